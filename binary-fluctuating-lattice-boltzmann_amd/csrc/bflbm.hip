@@ -1,0 +1,660 @@
+// bflbm.hip -- C-ABI implementation (include/bflbm.h) over the gfx950 kernels.
+// Host side: context, HBM layout, launches, FAB <-> slab copies.  No torch, no oracle.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/bflbm.h"
+#define BFLBM_NHYDRO_ 22
+#include "bflbm_kernels.h"
+#include "bflbm_fused.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return 1;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+const double kW[Q] = {1./3., 1./18.,1./18.,1./18.,1./18.,1./18.,1./18.,
+                      1./36.,1./36.,1./36.,1./36.,1./36.,1./36.,1./36.,1./36.,1./36.,1./36.,1./36.,1./36.};
+// mode norms b[a], LBM_d3q19.H:56-76
+const double kB[Q] = {1.0, 1./3., 1./3., 1./3., 2./3., 4./3., 4./9., 1./9., 1./9., 1./9.,
+                      2./3., 2./3., 2./3., 2./9., 2./9., 2./9., 2.0, 4./3., 4./9.};
+const int kCZh[Q] = BFLBM_CZ;
+
+// Uniform sub-expressions in the reference's operation order (see DevParams).
+void derive(const bflbm_params& p, DevParams& d) {
+  d.cs2 = p.cs2;
+  d.cs4 = p.cs2 * p.cs2;                       // LBM_d3q19.H:7 (1./3.)*(1./3.)
+  d.tau_f = p.tau_f; d.tau_g = p.tau_g; d.alpha0 = p.alpha0; d.kBT = p.kBT;
+  d.wcs1 = kW[1] / p.cs2;
+  d.wcs2 = kW[7] / p.cs2;
+  d.neg_cs2_alpha0 = -p.cs2 * p.alpha0;
+  d.kf = 0.5 / (p.tau_f + 0.5);
+  d.kg = 0.5 / (p.tau_g + 0.5);
+  const double tau_f_bar = p.tau_f * (1. + 0.5 / p.tau_f);
+  const double tau_g_bar = p.tau_g * (1. + 0.5 / p.tau_g);
+  d.inv_tau_f_bar = 1. / tau_f_bar;
+  d.inv_tau_g_bar = 1. / tau_g_bar;
+  d.coefC = 1. / p.cs2;
+  d.coefC_cs2 = d.coefC * p.cs2;
+  d.two_cs4 = 2. * d.cs4;
+  d.six_cs4 = 6. * d.cs4;
+  d.modifactor = 1. / (1. + 1. / (2. * p.tau_f));
+  d.mod2 = d.modifactor * 2.;
+  const double tfb = 1. / (p.tau_f + 0.5);     // LBM_binary.H:79-82 (tau_g_bar = tau_f_bar)
+  const double tfb2 = tfb * tfb;
+  const double base = 2. * (tfb - 0.5 * tfb2);
+  d.amp_j = base * p.kBT;
+  for (int a = 0; a < Q; ++a) {
+    d.amp_f[a] = base * p.kBT / p.cs2 * kB[a];
+    d.amp_g[a] = d.amp_f[a];
+  }
+  d.seed_lo = (uint32_t)p.seed;
+  d.seed_hi = (uint32_t)(p.seed >> 32);
+  d.noise_on = (p.kBT != 0.) ? 1 : 0;
+}
+
+}  // namespace
+
+struct bflbm_ctx {
+  bflbm_params prm;
+  DevParams dp;
+  bflbm_domain dom;
+  Geo G;
+  int nzl = 0;
+  double* S[2] = {nullptr, nullptr};
+  int cur = 0;
+  double* rho = nullptr;
+  double* phi = nullptr;
+  double* injf = nullptr;
+  double* injg = nullptr;
+  bool inject = false;
+  double* partial = nullptr;
+  size_t partial_n = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  long long steps = 0;
+  int schedule = 0;
+  bool step_open = false;
+  bool density_valid = false;   // rho/phi arrays hold the densities of the resident state
+  size_t bytes = 0;
+};
+
+namespace {
+
+dim3 plane_grid(const bflbm_ctx* c, int nplanes) {
+  return dim3((unsigned)((c->G.plane + 255) / 256), (unsigned)nplanes, 1);
+}
+
+// planes [pa,pb) of rho,phi from S[cur]
+int launch_density(bflbm_ctx* c, int pa, int pb) {
+  if (pb <= pa) return 0;
+  hipLaunchKernelGGL(k_density, plane_grid(c, pb - pa), dim3(256), 0, c->stream, c->S[c->cur], c->rho, c->phi, c->G, pa);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_collide(bflbm_ctx* c, int pa, int pb) {
+  if (pb <= pa) return 0;
+  const double* src = c->S[c->cur];
+  double* dst = c->S[1 - c->cur];
+  const uint32_t idx = (uint32_t)c->steps;
+  dim3 g = plane_grid(c, pb - pa), b(256);
+  if (c->inject)
+    hipLaunchKernelGGL((k_collide<true, true>), g, b, 0, c->stream, src, dst, c->rho, c->phi, c->injf, c->injg, c->G, c->dp, pa, idx);
+  else if (c->dp.noise_on)
+    hipLaunchKernelGGL((k_collide<true, false>), g, b, 0, c->stream, src, dst, c->rho, c->phi, c->injf, c->injg, c->G, c->dp, pa, idx);
+  else
+    hipLaunchKernelGGL((k_collide<false, false>), g, b, 0, c->stream, src, dst, c->rho, c->phi, c->injf, c->injg, c->G, c->dp, pa, idx);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_fused(bflbm_ctx* c, int pa, int pb) {
+  if (pb <= pa) return 0;
+  return fused_launch(c->S[c->cur], c->S[1 - c->cur], c->injf, c->injg, c->G, c->dp, pa, pb,
+                      (uint32_t)c->steps, c->inject ? 2 : (c->dp.noise_on ? 1 : 0), c->stream) ? fail("fused launch failed: %s", hipGetErrorString(hipGetLastError())) : 0;
+}
+
+// the slab's own planes are [H, H+nzl)
+inline int own_lo(const bflbm_ctx* c) { return c->G.H; }
+inline int own_hi(const bflbm_ctx* c) { return c->G.H + c->nzl; }
+
+int ensure_density(bflbm_ctx* c) {
+  if (c->density_valid) return 0;
+  const int ext = c->G.zwrap ? 0 : 1;
+  if (launch_density(c, own_lo(c) - ext, own_hi(c) + ext)) return 1;
+  c->density_valid = true;
+  return 0;
+}
+
+struct Overlap { int x0, x1, y0, y1, z0, z1; bool empty; };
+
+Overlap overlap(const bflbm_ctx* c, const bflbm_fab* b) {
+  Overlap o;
+  o.x0 = std::max(b->vlo[0], 0); o.x1 = std::min(b->vhi[0], c->G.nx - 1);
+  o.y0 = std::max(b->vlo[1], 0); o.y1 = std::min(b->vhi[1], c->G.ny - 1);
+  o.z0 = std::max(b->vlo[2], c->dom.z0); o.z1 = std::min(b->vhi[2], c->dom.z1 - 1);
+  o.empty = (o.x0 > o.x1 || o.y0 > o.y1 || o.z0 > o.z1);
+  return o;
+}
+
+int check_fab(const bflbm_fab* b) {
+  if (!b) return fail("null bflbm_fab");
+  for (int d = 0; d < 3; ++d) {
+    if (b->hi[d] < b->lo[d]) return fail("bflbm_fab: hi < lo in dim %d", d);
+    if (b->vlo[d] < b->lo[d] || b->vhi[d] > b->hi[d]) return fail("bflbm_fab: valid region outside the allocated box in dim %d", d);
+  }
+  return 0;
+}
+
+// copy ncomp components between a host FAB and a slab-layout device array (component stride
+// dvol, plane offset dplane0 = storage plane of global z0).  to_device selects direction.
+int copy_fab(bflbm_ctx* c, double* host, const bflbm_fab* b, int ncomp, double* dev, long long dvol, int dplane0, bool to_device) {
+  if (check_fab(b)) return 1;
+  const Overlap o = overlap(c, b);
+  if (o.empty) return 0;
+  const size_t fx = (size_t)(b->hi[0] - b->lo[0] + 1), fy = (size_t)(b->hi[1] - b->lo[1] + 1), fz = (size_t)(b->hi[2] - b->lo[2] + 1);
+  const size_t fvol = fx * fy * fz;
+  for (int k = 0; k < ncomp; ++k) {
+    hipMemcpy3DParms p;
+    memset(&p, 0, sizeof p);
+    hipPitchedPtr hp = make_hipPitchedPtr(host + (size_t)k * fvol, fx * sizeof(double), fx * sizeof(double), fy);
+    hipPitchedPtr dp = make_hipPitchedPtr(dev + (size_t)k * dvol, (size_t)c->G.nx * sizeof(double), (size_t)c->G.nx * sizeof(double), (size_t)c->G.ny);
+    hipPos hpos = make_hipPos((size_t)(o.x0 - b->lo[0]) * sizeof(double), (size_t)(o.y0 - b->lo[1]), (size_t)(o.z0 - b->lo[2]));
+    hipPos dpos = make_hipPos((size_t)o.x0 * sizeof(double), (size_t)o.y0, (size_t)(o.z0 - c->dom.z0 + dplane0));
+    p.extent = make_hipExtent((size_t)(o.x1 - o.x0 + 1) * sizeof(double), (size_t)(o.y1 - o.y0 + 1), (size_t)(o.z1 - o.z0 + 1));
+    if (to_device) { p.srcPtr = hp; p.srcPos = hpos; p.dstPtr = dp; p.dstPos = dpos; p.kind = hipMemcpyHostToDevice; }
+    else           { p.srcPtr = dp; p.srcPos = dpos; p.dstPtr = hp; p.dstPos = hpos; p.kind = hipMemcpyDeviceToHost; }
+    HIP_TRY(hipMemcpy3DAsync(&p, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// (component, storage plane) list of what crosses a z face.  pack side s gathers from the
+// slab's own planes; unpack side s scatters into the halo planes on that side.
+void halo_table(const bflbm_ctx* c, int kind, int side, bool pack, HaloTable& T) {
+  const int H = c->G.H, nzl = c->nzl;
+  int e = 0;
+  if (kind == BFLBM_HALO_UPLOAD) {
+    int plane;
+    if (pack) plane = (side == 0) ? H : H + nzl - 1;
+    else      plane = (side == 0) ? H - 1 : H + nzl;
+    for (int k = 0; k < 2 * Q; ++k) { T.comp[e] = k; T.plane[e] = plane; ++e; }
+    return;
+  }
+  // What the neighbour across `side` needs of MY planes (pack), i.e. what I receive into my
+  // halo from the neighbour across `side` (unpack, mirrored):
+  //  low face  (side 0, pack): plane H   : c_z in {0,-1};  plane H+1     : c_z = -1
+  //  high face (side 1, pack): plane H+nzl-1: c_z in {0,+1}; plane H+nzl-2: c_z = +1
+  //  unpack side 0 (from below): plane H-1: c_z in {0,+1};  plane H-2: c_z = +1
+  //  unpack side 1 (from above): plane H+nzl: c_z in {0,-1}; plane H+nzl+1: c_z = -1
+  int near, far, dir;
+  if (pack) { dir = (side == 0) ? -1 : +1; near = (side == 0) ? H : H + nzl - 1; far = (side == 0) ? H + 1 : H + nzl - 2; }
+  else      { dir = (side == 0) ? +1 : -1; near = (side == 0) ? H - 1 : H + nzl; far = (side == 0) ? H - 2 : H + nzl + 1; }
+  for (int fl = 0; fl < 2; ++fl) {
+    for (int i = 0; i < Q; ++i) if (kCZh[i] == 0 || kCZh[i] == dir) { T.comp[e] = fl * Q + i; T.plane[e] = near; ++e; }
+    for (int i = 0; i < Q; ++i) if (kCZh[i] == dir) { T.comp[e] = fl * Q + i; T.plane[e] = far; ++e; }
+  }
+}
+
+double* halo_buffer(bflbm_ctx* c, int kind) {
+  return (kind == BFLBM_HALO_STATE) ? c->S[c->cur] : c->S[1 - c->cur];
+}
+
+}  // namespace
+
+extern "C" {
+
+void bflbm_default_params(bflbm_params* p) {
+  p->tau_f = 1. / 2.; p->tau_g = 1. / 2.;
+  p->alpha0 = 4.; p->alpha1 = 0.;
+  p->kappa = 4;
+  p->kBT = 0.;
+  p->cs2 = 1. / 3.;
+  p->rho_lo = 0.; p->rho_hi = 1.0;
+  p->seed = 12345ULL;
+}
+
+int bflbm_abi_version(void) { return BFLBM_ABI_VERSION; }
+const char* bflbm_last_error(void) { return g_err.c_str(); }
+
+int bflbm_device_count(int* n) {
+  if (!n) return fail("null argument");
+  HIP_TRY(hipGetDeviceCount(n));
+  return 0;
+}
+
+int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) {
+  if (!p || !d || !out) return fail("bflbm_create: null argument");
+  if (d->n[0] < 1 || d->n[1] < 1 || d->n[2] < 1) return fail("bflbm_create: lattice size must be >= 1");
+  if (d->nranks < 1 || d->rank < 0 || d->rank >= d->nranks) return fail("bflbm_create: bad rank/nranks");
+  if (d->z0 < 0 || d->z1 > d->n[2] || d->z1 <= d->z0) return fail("bflbm_create: bad slab [%d,%d) of nz=%d", d->z0, d->z1, d->n[2]);
+  if (d->nranks == 1 && (d->z0 != 0 || d->z1 != d->n[2])) return fail("bflbm_create: a single slab must cover all of z");
+  if (d->nranks > 1 && d->z1 - d->z0 < 4) return fail("bflbm_create: a slab needs at least 4 planes when nranks > 1");
+  if ((long long)d->n[0] * d->n[1] * (long long)(d->z1 - d->z0 + 4) >= (1LL << 31)) return fail("bflbm_create: slab too large for 32-bit site offsets");
+  HIP_TRY(hipSetDevice(d->device));
+  bflbm_ctx* c = new bflbm_ctx();
+  c->prm = *p; c->dom = *d;
+  derive(c->prm, c->dp);
+  c->nzl = d->z1 - d->z0;
+  Geo& G = c->G;
+  G.nx = d->n[0]; G.ny = d->n[1]; G.nz = d->n[2];
+  G.zwrap = (d->nranks == 1) ? 1 : 0;
+  G.H = G.zwrap ? 0 : 2;
+  G.nzs = c->nzl + 2 * G.H;
+  G.z0 = d->z0;
+  G.plane = (long long)G.nx * G.ny;
+  G.vol = G.plane * G.nzs;
+  const size_t sbytes = (size_t)2 * Q * G.vol * sizeof(double);
+  const size_t fbytes = (size_t)G.vol * sizeof(double);
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipMalloc((void**)&c->S[k], sbytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->rho, fbytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->phi, fbytes);
+  c->partial_n = (size_t)((G.plane + 255) / 256) * (size_t)c->nzl;
+  if (e == hipSuccess) e = hipMalloc((void**)&c->partial, c->partial_n * 5 * sizeof(double));
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e != hipSuccess) {
+    fail("bflbm_create: %s", hipGetErrorString(e));
+    bflbm_destroy(c);
+    return 1;
+  }
+  c->bytes = 2 * sbytes + 2 * fbytes + c->partial_n * 5 * sizeof(double);
+  // halo planes must never hold NaN garbage that a reduction could touch
+  hipMemsetAsync(c->S[0], 0, sbytes, c->stream);
+  hipMemsetAsync(c->S[1], 0, sbytes, c->stream);
+  hipMemsetAsync(c->rho, 0, fbytes, c->stream);
+  hipMemsetAsync(c->phi, 0, fbytes, c->stream);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = c;
+  return 0;
+}
+
+int bflbm_destroy(bflbm_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->dom.device);
+  if (c->stream && c->own_stream) hipStreamSynchronize(c->stream);
+  for (int k = 0; k < 2; ++k) if (c->S[k]) hipFree(c->S[k]);
+  if (c->rho) hipFree(c->rho);
+  if (c->phi) hipFree(c->phi);
+  if (c->injf) hipFree(c->injf);
+  if (c->injg) hipFree(c->injg);
+  if (c->partial) hipFree(c->partial);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int bflbm_set_params(bflbm_ctx* c, const bflbm_params* p) {
+  if (!c || !p) return fail("null argument");
+  c->prm = *p;
+  derive(c->prm, c->dp);
+  return 0;
+}
+int bflbm_get_params(const bflbm_ctx* c, bflbm_params* p) {
+  if (!c || !p) return fail("null argument");
+  *p = c->prm;
+  return 0;
+}
+
+int bflbm_set_stream(bflbm_ctx* c, void* s) {
+  if (!c) return fail("null context");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (s) {
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)s; c->own_stream = false;
+  } else if (!c->own_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  return 0;
+}
+
+int bflbm_set_schedule(bflbm_ctx* c, int schedule) {
+  if (!c) return fail("null context");
+  if (schedule < 0 || schedule > 1) return fail("unknown schedule %d", schedule);
+  c->schedule = schedule;
+  return 0;
+}
+
+// ---- initial conditions ---------------------------------------------------------------
+static int run_init(bflbm_ctx* c, int mode, const double* rho_ext_host, size_t n_ext, double rho_c, double phi_c, double rho_t) {
+  HIP_TRY(hipSetDevice(c->dom.device));
+  double* scratch = c->S[1 - c->cur];
+  if (mode != 0) HIP_TRY(hipMemcpyAsync(scratch, rho_ext_host, n_ext * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_init, plane_grid(c, c->G.nzs), dim3(256), 0, c->stream, c->S[c->cur], scratch, c->G, mode, rho_c, phi_c, rho_t, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->steps = 0; c->density_valid = false; c->step_open = false;
+  return 0;
+}
+
+// global z of extended plane pe (pe = storage plane + 1), wrapped
+static inline int ext_global_z(const bflbm_ctx* c, int pe) {
+  int gz = c->dom.z0 - c->G.H + pe - 1;
+  const int nz = c->G.nz;
+  gz %= nz; if (gz < 0) gz += nz;
+  return gz;
+}
+
+int bflbm_init_mixture(bflbm_ctx* c) {
+  if (!c) return fail("null context");
+  const double C1 = 0.5, C2 = 0.5;               // LBM_binary.H:606-614
+  return run_init(c, 0, nullptr, 0, 2. * C1, 2. * C2, 0.);
+}
+
+int bflbm_init_stripe(bflbm_ctx* c, double frac) {
+  if (!c) return fail("null context");
+  const bflbm_params& P = c->prm;
+  const int nz = c->G.nz;
+  const double rho_t = P.rho_hi + P.rho_lo;      // LBM_binary.H:674-681
+  const double pos_lo = (-0.5 * frac) * nz;
+  const double pos_hi = (0.5 * frac) * nz;
+  std::vector<double> tab((size_t)c->G.nzs + 2);
+  for (int pe = 0; pe < c->G.nzs + 2; ++pe) {
+    const int z = ext_global_z(c, pe);
+    const double pos = z - nz / 2;
+    tab[pe] = (P.rho_hi - P.rho_lo) * 0.5 * (std::tanh((pos - pos_lo) / std::sqrt(P.kappa)) + std::tanh((pos_hi - pos) / std::sqrt(P.kappa))) + P.rho_lo;
+  }
+  return run_init(c, 1, tab.data(), tab.size(), 0., 0., rho_t);
+}
+
+int bflbm_init_droplet(bflbm_ctx* c, double r_frac) {
+  if (!c) return fail("null context");
+  const bflbm_params P = c->prm;
+  const int nx = c->G.nx, ny = c->G.ny;
+  const double R = r_frac * nx;                  // LBM_binary.H:714 (box[0])
+  const double rho_t = P.rho_hi + P.rho_lo;
+  const int npe = c->G.nzs + 2;
+  const size_t plane = (size_t)c->G.plane;
+  std::vector<double> fld(plane * npe);
+  auto work = [&](int pa, int pb) {
+    for (int pe = pa; pe < pb; ++pe) {
+      const int z = ext_global_z(c, pe);
+      const double rz = z - nx / 2;              // :725 box[0], integer division (sic)
+      for (int y = 0; y < ny; ++y) {
+        const double ry = y - ny / 2.;
+        for (int x = 0; x < nx; ++x) {
+          const double rx = x - nx / 2.;
+          const double r2 = rx * rx + ry * ry + rz * rz;
+          const double r = std::sqrt(r2);
+          fld[(size_t)pe * plane + (size_t)y * nx + x] = (P.rho_hi - P.rho_lo) * (1. + std::tanh((R - r) / std::sqrt(P.kappa))) / 2. + P.rho_lo;
+        }
+      }
+    }
+  };
+  unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+  if ((size_t)npe * plane < (1u << 18)) nt = 1;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t) {
+    const int pa = (int)((long long)npe * t / nt), pb = (int)((long long)npe * (t + 1) / nt);
+    if (pb > pa) th.emplace_back(work, pa, pb);
+  }
+  for (auto& t : th) t.join();
+  return run_init(c, 2, fld.data(), fld.size(), 0., 0., rho_t);
+}
+
+// ---- upload / download ----------------------------------------------------------------
+int bflbm_upload_fg(bflbm_ctx* c, const double* f, const double* g, const bflbm_fab* box) {
+  if (!c || !f || !g) return fail("null argument");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  double* N = c->S[1 - c->cur];
+  if (copy_fab(c, const_cast<double*>(f), box, Q, N, c->G.vol, c->G.H, true)) return 1;
+  if (copy_fab(c, const_cast<double*>(g), box, Q, N + (size_t)Q * c->G.vol, c->G.vol, c->G.H, true)) return 1;
+  return 0;
+}
+
+int bflbm_commit_upload(bflbm_ctx* c, int reset) {
+  if (!c) return fail("null context");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  hipLaunchKernelGGL(k_unstream, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[1 - c->cur], c->S[c->cur], c->G, own_lo(c));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (reset) c->steps = 0;
+  c->density_valid = false; c->step_open = false;
+  return 0;
+}
+
+int bflbm_download_fg(bflbm_ctx* c, double* f, double* g, const bflbm_fab* box) {
+  if (!c || !f || !g) return fail("null argument");
+  if (c->step_open) return fail("download inside an open step");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  double* N = c->S[1 - c->cur];
+  hipLaunchKernelGGL(k_pull, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], N, c->G, own_lo(c));
+  HIP_TRY(hipGetLastError());
+  if (copy_fab(c, f, box, Q, N, c->G.vol, c->G.H, false)) return 1;
+  if (copy_fab(c, g, box, Q, N + (size_t)Q * c->G.vol, c->G.vol, c->G.H, false)) return 1;
+  return 0;
+}
+
+// ---- time stepping --------------------------------------------------------------------
+int bflbm_step_boundary(bflbm_ctx* c) {
+  if (!c) return fail("null context");
+  if (c->step_open) return fail("step already open");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  c->step_open = true;
+  const int lo = own_lo(c), hi = own_hi(c);
+  if (c->G.zwrap) return 0;                      // single slab: everything is "interior"
+  if (c->schedule == 1) {
+    if (launch_fused(c, lo, lo + 2)) return 1;
+    return launch_fused(c, hi - 2, hi);
+  }
+  if (ensure_density(c)) return 1;
+  if (launch_collide(c, lo, lo + 2)) return 1;
+  return launch_collide(c, hi - 2, hi);
+}
+
+int bflbm_step_interior(bflbm_ctx* c) {
+  if (!c) return fail("null context");
+  if (!c->step_open) return fail("bflbm_step_interior: call bflbm_step_boundary first");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  const int lo = own_lo(c), hi = own_hi(c);
+  const int a = c->G.zwrap ? lo : lo + 2, b = c->G.zwrap ? hi : hi - 2;
+  if (c->schedule == 1) return launch_fused(c, a, b);
+  if (ensure_density(c)) return 1;
+  return launch_collide(c, a, b);
+}
+
+int bflbm_step_finish(bflbm_ctx* c) {
+  if (!c) return fail("null context");
+  if (!c->step_open) return fail("no open step");
+  c->cur = 1 - c->cur;
+  c->steps += 1;
+  c->step_open = false;
+  c->density_valid = false;
+  if (c->inject) c->inject = false;              // injected noise feeds exactly one step
+  return 0;
+}
+
+int bflbm_step(bflbm_ctx* c, int nsteps) {
+  if (!c) return fail("null context");
+  if (nsteps < 0) return fail("nsteps < 0");
+  if (!c->G.zwrap && nsteps > 1) return fail("bflbm_step: nranks > 1 needs a halo exchange between steps; use nsteps == 1");
+  for (int s = 0; s < nsteps; ++s) {
+    if (bflbm_step_boundary(c)) return 1;
+    if (bflbm_step_interior(c)) return 1;
+    if (bflbm_step_finish(c)) return 1;
+  }
+  return 0;
+}
+
+int bflbm_step_count(const bflbm_ctx* c, long long* n) {
+  if (!c || !n) return fail("null argument");
+  *n = c->steps;
+  return 0;
+}
+
+// ---- halo exchange support -------------------------------------------------------------
+int bflbm_halo_bytes(const bflbm_ctx* c, int kind, size_t* bytes) {
+  if (!c || !bytes) return fail("null argument");
+  if (kind < 0 || kind > 2) return fail("unknown halo kind %d", kind);
+  *bytes = (size_t)2 * Q * (size_t)c->G.plane * sizeof(double);
+  return 0;
+}
+
+int bflbm_halo_pack(bflbm_ctx* c, int kind, int side, void* buf) {
+  if (!c || !buf) return fail("null argument");
+  if (c->G.zwrap) return fail("halo exchange on a single slab");
+  if (kind < 0 || kind > 2 || side < 0 || side > 1) return fail("bad halo kind/side");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  HaloTable T; halo_table(c, kind, side, true, T);
+  hipLaunchKernelGGL(k_halo_pack, plane_grid(c, 2 * Q), dim3(256), 0, c->stream, halo_buffer(c, kind), (double*)buf, c->G, T);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int bflbm_halo_unpack(bflbm_ctx* c, int kind, int side, const void* buf) {
+  if (!c || !buf) return fail("null argument");
+  if (c->G.zwrap) return fail("halo exchange on a single slab");
+  if (kind < 0 || kind > 2 || side < 0 || side > 1) return fail("bad halo kind/side");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  HaloTable T; halo_table(c, kind, side, false, T);
+  hipLaunchKernelGGL(k_halo_unpack, plane_grid(c, 2 * Q), dim3(256), 0, c->stream, halo_buffer(c, kind), (const double*)buf, c->G, T);
+  HIP_TRY(hipGetLastError());
+  if (kind == BFLBM_HALO_STATE) c->density_valid = false;
+  return 0;
+}
+
+// ---- observables -----------------------------------------------------------------------
+static int observe(bflbm_ctx* c, int what, int ncomp_out, double* dst, double* dst2, int ncomp_host, const bflbm_fab* box) {
+  if (c->step_open) return fail("observables requested inside an open step");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  if (what == 2 && ensure_density(c)) return 1;
+  double* out = c->S[1 - c->cur];
+  dim3 g = plane_grid(c, c->nzl), b(256);
+  const uint32_t idx = (uint32_t)c->steps;
+  const int inj = c->inject ? 1 : 0;
+  if (what == 0) hipLaunchKernelGGL((k_observe<0>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj);
+  if (what == 1) hipLaunchKernelGGL((k_observe<1>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj);
+  if (what == 2) hipLaunchKernelGGL((k_observe<2>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj);
+  HIP_TRY(hipGetLastError());
+  const long long ovol = (long long)c->nzl * c->G.plane;
+  if (what == 1) {
+    if (dst && copy_fab(c, dst, box, Q, out, ovol, 0, false)) return 1;
+    if (dst2 && copy_fab(c, dst2, box, Q, out + (size_t)Q * ovol, ovol, 0, false)) return 1;
+    return 0;
+  }
+  return copy_fab(c, dst, box, ncomp_host, out, ovol, 0, false);
+}
+
+int bflbm_get_hydrovsbar(bflbm_ctx* c, double* dst, int ncomp, const bflbm_fab* box) {
+  if (!c || !dst) return fail("null argument");
+  if (ncomp < 1) return fail("ncomp < 1");
+  return observe(c, 0, BFLBM_NHYDROBAR, dst, nullptr, std::min(ncomp, BFLBM_NHYDROBAR), box);
+}
+int bflbm_get_hydrovs(bflbm_ctx* c, double* dst, int ncomp, const bflbm_fab* box) {
+  if (!c || !dst) return fail("null argument");
+  if (ncomp < 1) return fail("ncomp < 1");
+  const int n = std::min(ncomp, BFLBM_NHYDRO);
+  return observe(c, 2, n, dst, nullptr, n, box);
+}
+int bflbm_get_noise(bflbm_ctx* c, double* fn, double* gn, const bflbm_fab* box) {
+  if (!c) return fail("null context");
+  return observe(c, 1, 2 * Q, fn, gn, Q, box);
+}
+
+int bflbm_inject_noise(bflbm_ctx* c, const double* fn, const double* gn, const bflbm_fab* box) {
+  if (!c) return fail("null context");
+  if (!fn || !gn) { c->inject = false; return 0; }
+  HIP_TRY(hipSetDevice(c->dom.device));
+  const size_t nb = (size_t)Q * c->nzl * (size_t)c->G.plane * sizeof(double);
+  if (!c->injf) { HIP_TRY(hipMalloc((void**)&c->injf, nb)); HIP_TRY(hipMalloc((void**)&c->injg, nb)); c->bytes += 2 * nb; }
+  const long long ovol = (long long)c->nzl * c->G.plane;
+  if (copy_fab(c, const_cast<double*>(fn), box, Q, c->injf, ovol, 0, true)) return 1;
+  if (copy_fab(c, const_cast<double*>(gn), box, Q, c->injg, ovol, 0, true)) return 1;
+  c->inject = true;
+  return 0;
+}
+
+static int reduce5(bflbm_ctx* c, double out[5]) {
+  if (c->step_open) return fail("reduction requested inside an open step");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  if (ensure_density(c)) return 1;
+  hipLaunchKernelGGL(k_reduce, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->rho, c->phi, c->partial, c->G, own_lo(c));
+  HIP_TRY(hipGetLastError());
+  std::vector<double> h(c->partial_n * 5);
+  HIP_TRY(hipMemcpyAsync(h.data(), c->partial, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 5; ++k) out[k] = 0.;
+  for (size_t b = 0; b < c->partial_n; ++b) for (int k = 0; k < 5; ++k) out[k] += h[b * 5 + k];
+  return 0;
+}
+
+int bflbm_com_sums(bflbm_ctx* c, double sums[4]) {
+  if (!c || !sums) return fail("null argument");
+  double r[5];
+  if (reduce5(c, r)) return 1;
+  sums[0] = r[0]; sums[1] = r[2]; sums[2] = r[3]; sums[3] = r[4];
+  return 0;
+}
+
+int bflbm_mass(bflbm_ctx* c, double* rho_sum, double* phi_sum) {
+  if (!c || !rho_sum || !phi_sum) return fail("null argument");
+  double r[5];
+  if (reduce5(c, r)) return 1;
+  *rho_sum = r[0]; *phi_sum = r[1];
+  return 0;
+}
+
+int bflbm_sync(bflbm_ctx* c) {
+  if (!c) return fail("null context");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int bflbm_timer_start(bflbm_ctx* c) {
+  if (!c) return fail("null context");
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  return 0;
+}
+int bflbm_timer_stop(bflbm_ctx* c, float* ms) {
+  if (!c || !ms) return fail("null argument");
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+
+int bflbm_rng_site_normals(uint64_t seed, uint64_t site, uint32_t noise_index, double* out36) {
+  if (!out36) return fail("null argument");
+  for (uint32_t blk = 0; blk < 9; ++blk) {
+    float a, b, cc, d;
+    bflbm_rng_block((uint32_t)seed, (uint32_t)(seed >> 32), site, noise_index, blk, a, b, cc, d);
+    out36[4 * blk] = a; out36[4 * blk + 1] = b; out36[4 * blk + 2] = cc; out36[4 * blk + 3] = d;
+  }
+  return 0;
+}
+
+int bflbm_device_bytes(const bflbm_ctx* c, size_t* bytes) {
+  if (!c || !bytes) return fail("null argument");
+  *bytes = c->bytes;
+  return 0;
+}
+
+}  // extern "C"

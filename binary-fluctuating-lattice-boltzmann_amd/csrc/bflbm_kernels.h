@@ -1,0 +1,307 @@
+// bflbm_kernels.h -- HIP kernels (gfx950) of the collide-and-stream path.
+//
+// Resident state: S[c][p][y][x], c = 0..18 fluid f, 19..37 fluid g, x fastest,
+// holding the POST-COLLISION populations; the reference's post-stream state
+// (fold/gold after LBM_timestep) is recovered by the pull  f_i(x) = S_i(x - c_i),
+// which the survey verified to be bit-identical to the reference's
+// collide-on-(valid+1 ghost)-then-push (LBM_binary.H:519-542).
+// p is the storage plane: p = z - z0 + H, H halo planes per side (0 when the
+// slab is the whole periodic box and z wraps inside the kernel).
+#ifndef BFLBM_KERNELS_H_
+#define BFLBM_KERNELS_H_
+
+#include "bflbm_site.h"
+
+struct Geo {
+  int nx, ny, nzs;     // storage extent (nzs includes the halo planes)
+  int zwrap;           // 1: plane neighbours wrap modulo nzs (single slab)
+  int H;               // halo planes per side
+  int z0;              // global z of storage plane H
+  int nz;              // global nz
+  long long plane;     // nx*ny
+  long long vol;       // nzs*plane = component stride
+};
+
+__device__ __constant__ const int kCX[Q] = BFLBM_CX;
+__device__ __constant__ const int kCY[Q] = BFLBM_CY;
+__device__ __constant__ const int kCZ[Q] = BFLBM_CZ;
+
+// compile-time velocity tables for fully unrolled loops
+struct Vel {
+  static constexpr int cx[Q] = BFLBM_CX;
+  static constexpr int cy[Q] = BFLBM_CY;
+  static constexpr int cz[Q] = BFLBM_CZ;
+};
+
+struct SiteIdx {
+  int x, y, p;
+  int xm, xp;          // x-1, x+1 wrapped
+  long long row[3][3]; // row[dz+1][dy+1] = (p+dz)*plane + (y+dy wrapped)*nx
+};
+
+__device__ __forceinline__ void site_index(const Geo& G, int x, int y, int p, SiteIdx& I) {
+  I.x = x; I.y = y; I.p = p;
+  I.xm = (x == 0) ? G.nx - 1 : x - 1;
+  I.xp = (x == G.nx - 1) ? 0 : x + 1;
+  const int ym = (y == 0) ? G.ny - 1 : y - 1;
+  const int yp = (y == G.ny - 1) ? 0 : y + 1;
+  int pm = p - 1, pp = p + 1;
+  if (G.zwrap) { if (pm < 0) pm = G.nzs - 1; if (pp >= G.nzs) pp = 0; }
+  const int ys[3] = { ym, y, yp };
+  const int ps[3] = { pm, p, pp };
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) I.row[a][b] = (long long)ps[a]*G.plane + (long long)ys[b]*G.nx;
+}
+
+// offset of the site displaced by (dx,dy,dz) in {-1,0,1}^3 (compile-time constants after unrolling)
+__device__ __forceinline__ long long nb_off(const SiteIdx& I, int dx, int dy, int dz) {
+  const int xx = dx > 0 ? I.xp : (dx < 0 ? I.xm : I.x);
+  return I.row[dz+1][dy+1] + xx;
+}
+
+// f_i(x) = S_i(x - c_i)
+__device__ __forceinline__ void pull_site(const double* __restrict__ S, const Geo& G, const SiteIdx& I,
+                                          double (&fs)[Q], double (&gs)[Q]) {
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    const long long o = nb_off(I, -Vel::cx[i], -Vel::cy[i], -Vel::cz[i]);
+    fs[i] = S[(long long)i*G.vol + o];
+    gs[i] = S[(long long)(i+Q)*G.vol + o];
+  }
+}
+
+// nb[i] = field(x + c_i)
+__device__ __forceinline__ void gather_field(const double* __restrict__ fld, const SiteIdx& I, double (&nb)[Q]) {
+#pragma unroll
+  for (int i = 0; i < Q; ++i) nb[i] = fld[nb_off(I, Vel::cx[i], Vel::cy[i], Vel::cz[i])];
+}
+
+__device__ __forceinline__ uint64_t global_site(const Geo& G, int x, int y, int p) {
+  int gz = G.z0 + (p - G.H);
+  if (gz < 0) gz += G.nz;
+  if (gz >= G.nz) gz -= G.nz;
+  return (uint64_t)x + (uint64_t)G.nx*((uint64_t)y + (uint64_t)G.ny*(uint64_t)gz);
+}
+
+#define BFLBM_SITE_FROM_BLOCK()                                         \
+  const long long s_ = (long long)blockIdx.x*blockDim.x + threadIdx.x;  \
+  if (s_ >= G.plane) return;                                            \
+  const int p = p0 + (int)blockIdx.y;                                   \
+  const int y = (int)(s_ / G.nx);                                       \
+  const int x = (int)(s_ - (long long)y*G.nx);
+
+// ---- pass A of the two-pass schedule: rho,phi of the streamed state (LBM_binary.H:320-330)
+__global__ void __launch_bounds__(256) k_density(const double* __restrict__ S, double* __restrict__ rho,
+                                                 double* __restrict__ phi, Geo G, int p0) {
+  BFLBM_SITE_FROM_BLOCK();
+  SiteIdx I; site_index(G, x, y, p, I);
+  double fs[Q], gs[Q];
+  pull_site(S, G, I, fs, gs);
+  const long long o = I.row[1][1] + x;
+  rho[o] = d_density(fs);
+  phi[o] = d_density(gs);
+}
+
+// ---- pass B: pull, project (hydrovars), draw noise, collide, store post-collision state
+template <bool NOISE, bool INJECT>
+__global__ void __launch_bounds__(256) k_collide(const double* __restrict__ S, double* __restrict__ D,
+                                                 const double* __restrict__ rho, const double* __restrict__ phi,
+                                                 const double* __restrict__ injf, const double* __restrict__ injg,
+                                                 Geo G, DevParams P, int p0, uint32_t noise_index) {
+  BFLBM_SITE_FROM_BLOCK();
+  SiteIdx I; site_index(G, x, y, p, I);
+  double fs[Q], gs[Q];
+  pull_site(S, G, I, fs, gs);
+  const long long o = I.row[1][1] + x;
+  const double r = rho[o], ph = phi[o];
+  double nb[Q], grad_rho[3], grad_phi[3];
+  gather_field(rho, I, nb); d_gradient(P, nb, grad_rho);
+  gather_field(phi, I, nb); d_gradient(P, nb, grad_phi);
+  double fn[Q], gn[Q];
+  if (INJECT) {
+    // injected arrays are dense over the slab's own planes: [a][p-H][y][x]
+    const long long nvol = (long long)(G.nzs - 2*G.H)*G.plane;
+    const long long no = (long long)(p - G.H)*G.plane + (long long)y*G.nx + x;
+#pragma unroll
+    for (int a = 0; a < Q; ++a) { fn[a] = injf[a*nvol + no]; gn[a] = injg[a*nvol + no]; }
+  } else if (NOISE) {
+    d_noise(P, r, ph, global_site(G, x, y, p), noise_index, fn, gn);
+  } else {
+#pragma unroll
+    for (int a = 0; a < Q; ++a) { fn[a] = 0.; gn[a] = 0.; }
+  }
+  SiteHydro Hy;
+  d_hydrovars(P, fs, gs, r, ph, grad_rho, grad_phi, fn, gn, Hy);
+  d_collide<NOISE || INJECT>(P, fs, gs, r, ph, Hy, fn, gn);
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    D[(long long)i*G.vol + o] = fs[i];
+    D[(long long)(i+Q)*G.vol + o] = gs[i];
+  }
+}
+
+// ---- natural (post-stream) populations of the slab's own planes: N_i(x) = S_i(x - c_i)
+__global__ void __launch_bounds__(256) k_pull(const double* __restrict__ S, double* __restrict__ N, Geo G, int p0) {
+  BFLBM_SITE_FROM_BLOCK();
+  SiteIdx I; site_index(G, x, y, p, I);
+  double fs[Q], gs[Q];
+  pull_site(S, G, I, fs, gs);
+  const long long o = I.row[1][1] + x;
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    N[(long long)i*G.vol + o] = fs[i];
+    N[(long long)(i+Q)*G.vol + o] = gs[i];
+  }
+}
+
+// ---- inverse: S_i(x) = N_i(x + c_i)  (upload of fold/gold, LBM_binary.H:643)
+__global__ void __launch_bounds__(256) k_unstream(const double* __restrict__ N, double* __restrict__ S, Geo G, int p0) {
+  BFLBM_SITE_FROM_BLOCK();
+  SiteIdx I; site_index(G, x, y, p, I);
+  const long long o = I.row[1][1] + x;
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    const long long src = nb_off(I, Vel::cx[i], Vel::cy[i], Vel::cz[i]);
+    S[(long long)i*G.vol + o] = N[(long long)i*G.vol + src];
+    S[(long long)(i+Q)*G.vol + o] = N[(long long)(i+Q)*G.vol + src];
+  }
+}
+
+// ---- initial state: f_i = w_i rho, g_i = w_i phi (LBM_binary.H:615-618, :682-685, :733-736)
+// stored un-streamed: S_i(x) = w_i rho(x + c_i).  mode 0: uniform rho_c/phi_c; mode 1: rho from a
+// per-plane table (ext plane index p+1+dz); mode 2: rho from a full field with nzs+2 planes.
+__global__ void __launch_bounds__(256) k_init(double* __restrict__ S, const double* __restrict__ rho_ext,
+                                              Geo G, int mode, double rho_c, double phi_c, double rho_t, int p0) {
+  BFLBM_SITE_FROM_BLOCK();
+  const int xm = (x == 0) ? G.nx - 1 : x - 1, xp = (x == G.nx - 1) ? 0 : x + 1;
+  const int ym = (y == 0) ? G.ny - 1 : y - 1, yp = (y == G.ny - 1) ? 0 : y + 1;
+  const long long o = (long long)p*G.plane + (long long)y*G.nx + x;
+  const double w0 = 1./3., w1 = 1./18., w2 = 1./36.;
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    const double w = (i == 0) ? w0 : (i < 7 ? w1 : w2);
+    double r, ph;
+    if (mode == 0) { r = rho_c; ph = phi_c; }
+    else {
+      const int pe = p + 1 + Vel::cz[i];
+      if (mode == 1) r = rho_ext[pe];
+      else {
+        const int xx = Vel::cx[i] > 0 ? xp : (Vel::cx[i] < 0 ? xm : x);
+        const int yy = Vel::cy[i] > 0 ? yp : (Vel::cy[i] < 0 ? ym : y);
+        r = rho_ext[(long long)pe*G.plane + (long long)yy*G.nx + xx];
+      }
+      ph = rho_t - r;
+    }
+    S[(long long)i*G.vol + o] = w*r;
+    S[(long long)(i+Q)*G.vol + o] = w*ph;
+  }
+}
+
+// ---- materialise hydrovsbar / noise / hydrovs for the streamed state (own planes, dense output)
+// what: 0 hydrovsbar[9] (LBM_binary.H:315-340), 1 noise f,g [38] (:73-132), 2 hydrovs[ncomp] (:196-295)
+template <int WHAT>
+__global__ void __launch_bounds__(256) k_observe(const double* __restrict__ S, const double* __restrict__ rho,
+                                                 const double* __restrict__ phi, const double* __restrict__ injf,
+                                                 const double* __restrict__ injg, double* __restrict__ out,
+                                                 Geo G, DevParams P, int p0, uint32_t noise_index, int ncomp, int inject) {
+  BFLBM_SITE_FROM_BLOCK();
+  SiteIdx I; site_index(G, x, y, p, I);
+  double fs[Q], gs[Q];
+  pull_site(S, G, I, fs, gs);
+  const long long ovol = (long long)(G.nzs - 2*G.H)*G.plane;
+  const long long oo = (long long)(p - G.H)*G.plane + (long long)y*G.nx + x;
+  const double r = d_density(fs), ph = d_density(gs);
+  if (WHAT == 0) {
+    double mf[Q], mg[Q];
+    d_moments(fs, mf); d_moments(gs, mg);
+    out[0*ovol + oo] = r;
+    out[1*ovol + oo] = ph;
+    const bool okf = fabs(mf[0]) > (double)FLT_EPSILON, okg = fabs(mg[0]) > (double)FLT_EPSILON;
+#pragma unroll
+    for (int k = 1; k <= 3; ++k) {
+      out[(long long)(k+1)*ovol + oo] = okf ? mf[k]/mf[0] : 0.;
+      out[(long long)(k+5)*ovol + oo] = okg ? mg[k]/mg[0] : 0.;
+    }
+    out[5*ovol + oo] = mf[0] + mg[0];
+    return;
+  }
+  double fn[Q], gn[Q];
+  if (inject) {
+#pragma unroll
+    for (int a = 0; a < Q; ++a) { fn[a] = injf[a*ovol + oo]; gn[a] = injg[a*ovol + oo]; }
+  } else if (P.noise_on) {
+    d_noise(P, r, ph, global_site(G, x, y, p), noise_index, fn, gn);
+  } else {
+#pragma unroll
+    for (int a = 0; a < Q; ++a) { fn[a] = 0.; gn[a] = 0.; }
+  }
+  if (WHAT == 1) {
+#pragma unroll
+    for (int a = 0; a < Q; ++a) { out[(long long)a*ovol + oo] = fn[a]; out[(long long)(a+Q)*ovol + oo] = gn[a]; }
+    return;
+  }
+  double nb[Q], grad_rho[3], grad_phi[3];
+  gather_field(rho, I, nb); d_gradient(P, nb, grad_rho);
+  gather_field(phi, I, nb); d_gradient(P, nb, grad_phi);
+  SiteHydro Hy;
+  d_hydrovars(P, fs, gs, r, ph, grad_rho, grad_phi, fn, gn, Hy);
+  double h[BFLBM_NHYDRO_];
+  h[0] = r; h[1] = ph; h[5] = r + ph;
+  const double rho_tot = r + ph;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    h[2+k] = Hy.uf[k]; h[6+k] = Hy.ug[k]; h[9+k] = Hy.af[k]; h[12+k] = Hy.ag[k];
+    h[15+k] = (r*Hy.ufbar[k] + ph*Hy.ugbar[k] + 0.5*(r*Hy.af[k] + ph*Hy.ag[k]))/rho_tot;
+  }
+  h[18] = Hy.nfvel[0]; h[19] = Hy.ngvel[0]; h[20] = Hy.ufbar[0]; h[21] = Hy.ugbar[0];
+#pragma unroll
+  for (int k = 0; k < BFLBM_NHYDRO_; ++k) if (k < ncomp) out[(long long)k*ovol + oo] = h[k];
+}
+
+// ---- halo pack / unpack: 38 (component, plane) entries, each one contiguous nx*ny plane
+struct HaloTable { int comp[38]; int plane[38]; };
+
+__global__ void __launch_bounds__(256) k_halo_pack(const double* __restrict__ S, double* __restrict__ buf, Geo G, HaloTable T) {
+  const long long s = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (s >= G.plane) return;
+  const int e = blockIdx.y;
+  buf[(long long)e*G.plane + s] = S[(long long)T.comp[e]*G.vol + (long long)T.plane[e]*G.plane + s];
+}
+__global__ void __launch_bounds__(256) k_halo_unpack(double* __restrict__ S, const double* __restrict__ buf, Geo G, HaloTable T) {
+  const long long s = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (s >= G.plane) return;
+  const int e = blockIdx.y;
+  S[(long long)T.comp[e]*G.vol + (long long)T.plane[e]*G.plane + s] = buf[(long long)e*G.plane + s];
+}
+
+// ---- slab reductions (deterministic: per-block partials, summed on the host in block order)
+// out[b][0..5] = sum rho, sum phi, sum rho*i, sum rho*j, sum rho*k (global k), 0
+__global__ void __launch_bounds__(256) k_reduce(const double* __restrict__ rho, const double* __restrict__ phi,
+                                                double* __restrict__ partial, Geo G, int p0) {
+  __shared__ double sh[5][256];
+  const long long s_ = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+  const int p = p0 + (int)blockIdx.y;
+  double v[5] = {0., 0., 0., 0., 0.};
+  if (s_ < G.plane) {
+    const int y = (int)(s_ / G.nx);
+    const int x = (int)(s_ - (long long)y*G.nx);
+    const long long o = (long long)p*G.plane + s_;
+    const double r = rho[o];
+    int gz = G.z0 + (p - G.H);
+    v[0] = r; v[1] = phi[o]; v[2] = r*x; v[3] = r*y; v[4] = r*gz;
+  }
+  for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] = v[k];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const long long b = (long long)blockIdx.y*gridDim.x + blockIdx.x;
+    for (int k = 0; k < 5; ++k) partial[b*5 + k] = sh[k][0];
+  }
+}
+
+#endif  // BFLBM_KERNELS_H_

@@ -1,0 +1,357 @@
+// bflbm_site.h -- per-site arithmetic of the D3Q19 binary fluctuating-LBM step for gfx950.
+//
+// Every expression keeps the floating-point operation order of the reference
+// (file:line cited per function) and this translation unit is compiled with
+// -ffp-contract=off, so results are bit-identical to the reference's CPU build.
+// Uniform sub-expressions (those that depend only on the model parameters) are
+// evaluated once on the host, in the reference's order, into DevParams.
+#ifndef BFLBM_SITE_H_
+#define BFLBM_SITE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include "bflbm_rng.h"
+
+#define Q 19
+
+// Velocity set, reference order (LBM_d3q19.H:12-32).
+#define BFLBM_CX {0, 1,-1, 0, 0, 0, 0, 1,-1, 1,-1, 0, 0, 0, 0, 1,-1, 1,-1}
+#define BFLBM_CY {0, 0, 0, 1,-1, 0, 0, 1,-1,-1, 1, 1,-1, 1,-1, 0, 0, 0, 0}
+#define BFLBM_CZ {0, 0, 0, 0, 0, 1,-1, 0, 0, 0, 0, 1,-1,-1, 1, 1,-1,-1, 1}
+
+struct DevParams {
+  // model constants (LBM_binary.H:17-30, LBM_d3q19.H:6-10)
+  double cs2, cs4, tau_f, tau_g, alpha0, kBT;
+  // uniform sub-expressions, evaluated on the host in the reference's order
+  double wcs1, wcs2;            // w[1]/cs2, w[7]/cs2                (LBM_binary.H:143)
+  double neg_cs2_alpha0;        // -cs2*alpha0                       (:254-255)
+  double kf, kg;                // 0.5/(tau_f+0.5), 0.5/(tau_g+0.5)  (:266, :270)
+  double inv_tau_f_bar, inv_tau_g_bar;   // 1./tau_f_bar, 1./tau_g_bar (:504-508)
+  double coefC;                 // 1./cs2                            (:366, :414)
+  double coefC_cs2;             // coefC*cs2                         (:383)
+  double two_cs4, six_cs4;      // 2.*cs4, 6.*cs4                    (:387-389)
+  double modifactor;            // 1./(1.+1./(2.*tau_f))             (:424)
+  double mod2;                  // modifactor*2.                     (:431, :433)
+  double amp_j;                 // 2.*(tfb-0.5*tfb2)*kBT             (:117)
+  double amp_f[Q], amp_g[Q];    // 2.*(tfb-0.5*tfb2)*kBT/cs2*b[a]    (:125-126)
+  uint32_t seed_lo, seed_hi;
+  int noise_on;                 // kBT != 0
+};
+
+// populations -> moments (LBM_d3q19.H:100-156)
+__device__ __forceinline__ void d_moments(const double (&fs)[Q], double (&m)[Q]) {
+  double f;
+  double mc0, mc1, mc2;
+  double mx1, my1, mz1, mx2, my2, mz2, mx3, my3, mz3;
+  double mxy, mxz, myz, mxx1, myy1, mzz1, mxx2, myy2, mzz2;
+  f = fs[0];  mc0 = f;
+  f = fs[1];  mx1 = f;  mxx1 = f;
+  f = fs[2];  mx1 -= f; mxx1 += f;
+  f = fs[3];  my1 = f;  myy1 = f;
+  f = fs[4];  my1 -= f; myy1 += f;
+  f = fs[5];  mz1 = f;  mzz1 = f;
+  f = fs[6];  mz1 -= f; mzz1 += f;
+  f = fs[7];  mx2 = f;  my3 = f;  mxy = f;  mxx2 = f;
+  f = fs[8];  mx2 -= f; my3 -= f; mxy += f; mxx2 += f;
+  f = fs[9];  mx2 += f; my3 -= f; mxy -= f; mxx2 += f;
+  f = fs[10]; mx2 -= f; my3 += f; mxy -= f; mxx2 += f;
+  f = fs[11]; my2 = f;  mz3 = f;  myz = f;  myy2 = f;
+  f = fs[12]; my2 -= f; mz3 -= f; myz += f; myy2 += f;
+  f = fs[13]; my2 += f; mz3 -= f; myz -= f; myy2 += f;
+  f = fs[14]; my2 -= f; mz3 += f; myz -= f; myy2 += f;
+  f = fs[15]; mz2 = f;  mx3 = f;  mxz = f;  mzz2 = f;
+  f = fs[16]; mz2 -= f; mx3 -= f; mxz += f; mzz2 += f;
+  f = fs[17]; mz2 -= f; mx3 += f; mxz -= f; mzz2 += f;
+  f = fs[18]; mz2 += f; mx3 -= f; mxz -= f; mzz2 += f;
+  mc1 = mxx1 + myy1 + mzz1;
+  mc2 = mxx2 + myy2 + mzz2;
+  m[0]  = mc0 + mc1 + mc2;
+  m[1]  = mx1 + mx2 + mx3;
+  m[2]  = my1 + my2 + my3;
+  m[3]  = mz1 + mz2 + mz3;
+  m[4]  = mc2 - mc0;
+  m[5]  = 3.*mxx1 - mc1 + mc2 - 3.*myy2;
+  m[6]  = myy1 - mzz1 + mxx2 - mzz2;
+  m[7]  = mxy;
+  m[8]  = myz;
+  m[9]  = mxz;
+  m[10] = m[1] - 3.*mx1;
+  m[11] = m[2] - 3.*my1;
+  m[12] = m[3] - 3.*mz1;
+  m[13] = mx2 - mx3;
+  m[14] = my2 - my3;
+  m[15] = mz2 - mz3;
+  m[16] = m[0] - 3.*mc1;
+  m[17] = mc1 - 3.*mxx1 + mc2 - 3.*myy2;
+  m[18] = mzz1 - myy1 + mxx2 - mzz2;
+}
+
+// moments -> populations (LBM_d3q19.H:167-247)
+__device__ __forceinline__ void d_populations(const double (&mom)[Q], double (&f)[Q]) {
+  double m[Q];
+  m[0]  = mom[0]  / 36.;
+  m[1]  = mom[1]  / 12.;
+  m[2]  = mom[2]  / 12.;
+  m[3]  = mom[3]  / 12.;
+  m[4]  = mom[4]  / 24.;
+  m[5]  = mom[5]  / 48.;
+  m[6]  = mom[6]  / 16.;
+  m[7]  = mom[7]  / 4.;
+  m[8]  = mom[8]  / 4.;
+  m[9]  = mom[9]  / 4.;
+  m[10] = mom[10] / 24.;
+  m[11] = mom[11] / 24.;
+  m[12] = mom[12] / 24.;
+  m[13] = mom[13] / 8.;
+  m[14] = mom[14] / 8.;
+  m[15] = mom[15] / 8.;
+  m[16] = mom[16] / 72.;
+  m[17] = mom[17] / 48.;
+  m[18] = mom[18] / 16.;
+
+  const double mc0 = 12.*(m[0] - m[4] + m[16]);
+  const double mc1 =  2.*(m[0] - 2.*m[16]);
+  const double mc2 = m[0] + m[4] + m[16];
+  const double mx1 = 2.*(m[1] - 2.*m[10]);
+  const double my1 = 2.*(m[2] - 2.*m[11]);
+  const double mz1 = 2.*(m[3] - 2.*m[12]);
+  const double mx2 = m[1] + m[10] + m[13];
+  const double my2 = m[2] + m[11] + m[14];
+  const double mz2 = m[3] + m[12] + m[15];
+  const double mx3 = m[1] + m[10] - m[13];
+  const double my3 = m[2] + m[11] - m[14];
+  const double mz3 = m[3] + m[12] - m[15];
+  const double mxx1 = mc1 + 4.*(m[5] - m[17]);
+  const double myy1 = mc1 - 2.*(m[5] - m[6]) + 2.*(m[17] - m[18]);
+  const double mzz1 = mc1 - 2.*(m[5] + m[6]) + 2.*(m[17] + m[18]);
+  const double mxy2 = mc2 + (m[5] + m[6]) + (m[17] + m[18]);
+  const double mxz2 = mc2 + (m[5] - m[6]) + (m[17] - m[18]);
+  const double myz2 = mc2 - 2.*(m[5] + m[17]);
+  const double mxy = m[7];
+  const double myz = m[8];
+  const double mxz = m[9];
+
+  f[0]  = mc0;
+  f[1]  = mxx1 + mx1;
+  f[2]  = mxx1 - mx1;
+  f[3]  = myy1 + my1;
+  f[4]  = myy1 - my1;
+  f[5]  = mzz1 + mz1;
+  f[6]  = mzz1 - mz1;
+  f[7]  = mxy2 + mx2 + my3 + mxy;
+  f[8]  = mxy2 - mx2 - my3 + mxy;
+  f[9]  = mxy2 + mx2 - my3 - mxy;
+  f[10] = mxy2 - mx2 + my3 - mxy;
+  f[11] = myz2 + my2 + mz3 + myz;
+  f[12] = myz2 - my2 - mz3 + myz;
+  f[13] = myz2 + my2 - mz3 - myz;
+  f[14] = myz2 - my2 + mz3 - myz;
+  f[15] = mxz2 + mz2 + mx3 + mxz;
+  f[16] = mxz2 - mz2 - mx3 + mxz;
+  f[17] = mxz2 - mz2 + mx3 - mxz;
+  f[18] = mxz2 + mz2 - mx3 - mxz;
+}
+
+// rho = sum_i f_i in index order (hydrovars_bar_density, LBM_binary.H:320-328)
+__device__ __forceinline__ double d_density(const double (&fs)[Q]) {
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < Q; ++i) r += fs[i];
+  return r;
+}
+
+// j = sum_i f_i c_i in index order (hydrovars, LBM_binary.H:218-228): terms with c=0 add +-0.
+__device__ __forceinline__ void d_momentum(const double (&fs)[Q], double (&j)[3]) {
+  double jx = 0.0, jy = 0.0, jz = 0.0;
+  jx += fs[1];  jx -= fs[2];
+  jy += fs[3];  jy -= fs[4];
+  jz += fs[5];  jz -= fs[6];
+  jx += fs[7];  jy += fs[7];
+  jx -= fs[8];  jy -= fs[8];
+  jx += fs[9];  jy -= fs[9];
+  jx -= fs[10]; jy += fs[10];
+  jy += fs[11]; jz += fs[11];
+  jy -= fs[12]; jz -= fs[12];
+  jy += fs[13]; jz -= fs[13];
+  jy -= fs[14]; jz += fs[14];
+  jx += fs[15]; jz += fs[15];
+  jx -= fs[16]; jz -= fs[16];
+  jx += fs[17]; jz -= fs[17];
+  jx -= fs[18]; jz += fs[18];
+  j[0] = jx; j[1] = jy; j[2] = jz;
+}
+
+// gradient (LBM_binary.H:134-150, use_SC_pseudo=false) from the 18 neighbour values
+// nb[i] = field(x + c_i); nb[0] is unused (c_0 = 0 contributes +-0).
+__device__ __forceinline__ void d_gradient(const DevParams& P, const double (&nb)[Q], double (&g)[3]) {
+  double t[Q];
+#pragma unroll
+  for (int i = 1; i < 7; ++i) t[i] = P.wcs1 * nb[i];
+#pragma unroll
+  for (int i = 7; i < Q; ++i) t[i] = P.wcs2 * nb[i];
+  double gx = 0.0, gy = 0.0, gz = 0.0;
+  gx += t[1];  gx -= t[2];
+  gy += t[3];  gy -= t[4];
+  gz += t[5];  gz -= t[6];
+  gx += t[7];  gy += t[7];
+  gx -= t[8];  gy -= t[8];
+  gx += t[9];  gy -= t[9];
+  gx -= t[10]; gy += t[10];
+  gy += t[11]; gz += t[11];
+  gy -= t[12]; gz -= t[12];
+  gy += t[13]; gz -= t[13];
+  gy -= t[14]; gz += t[14];
+  gx += t[15]; gz += t[15];
+  gx -= t[16]; gz -= t[16];
+  gx += t[17]; gz -= t[17];
+  gx -= t[18]; gz += t[18];
+  g[0] = gx; g[1] = gy; g[2] = gz;
+}
+
+// thermal_noise (LBM_binary.H:73-132) for one site: 3 + 2*15 draws in the reference's order.
+__device__ __forceinline__ void d_noise(const DevParams& P, double rho, double phi, uint64_t site,
+                                        uint32_t noise_index, double (&fn)[Q], double (&gn)[Q]) {
+  float nrm[36];
+#pragma unroll
+  for (uint32_t blk = 0; blk < 9; ++blk)
+    bflbm_rng_block(P.seed_lo, P.seed_hi, site, noise_index, blk, nrm[4*blk], nrm[4*blk+1], nrm[4*blk+2], nrm[4*blk+3]);
+  const double rhot = rho + phi;
+  fn[0] = 0.; gn[0] = 0.;
+  const double sj = sqrt(P.amp_j * fabs(rho*phi/rhot));
+#pragma unroll
+  for (int a = 1; a <= 3; ++a) {
+    fn[a] = sj * (double)nrm[a-1];
+    gn[a] = -fn[a];
+  }
+  const double arho = fabs(rho), aphi = fabs(phi);
+#pragma unroll
+  for (int a = 4; a < Q; ++a) {
+    fn[a] = sqrt(P.amp_f[a] * arho) * (double)nrm[3 + 2*(a-4)];
+    gn[a] = sqrt(P.amp_g[a] * aphi) * (double)nrm[4 + 2*(a-4)];
+  }
+}
+
+// The quantities hydrovars() derives per site (LBM_binary.H:196-295) that collide() consumes.
+struct SiteHydro {
+  double uf[3], ug[3];        // h[2..4], h[6..8]  real velocities
+  double af[3], ag[3];        // h[9..11], h[12..14]
+  double ufbar[3], ugbar[3];  // lattice velocities
+  double nfvel[3], ngvel[3];
+};
+
+__device__ __forceinline__ void d_hydrovars(const DevParams& P, const double (&fs)[Q], const double (&gs)[Q],
+                                            double rho, double phi,
+                                            const double (&grad_rho)[3], const double (&grad_phi)[3],
+                                            const double (&nf)[Q], const double (&ng)[Q], SiteHydro& H) {
+  double jf[3], jg[3];
+  d_momentum(fs, jf);
+  d_momentum(gs, jg);
+  const bool okr = fabs(rho) > (double)FLT_EPSILON;
+  const bool okp = fabs(phi) > (double)FLT_EPSILON;
+  const double wphi = P.kf*phi/(rho+phi);
+  const double wrho = P.kg*rho/(rho+phi);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    H.ufbar[k] = okr ? jf[k]/rho : 0.;
+    H.ugbar[k] = okp ? jg[k]/phi : 0.;
+    H.af[k] = okr ? P.neg_cs2_alpha0*rho*grad_phi[k]/rho : 0.;
+    H.ag[k] = okp ? P.neg_cs2_alpha0*phi*grad_rho[k]/phi : 0.;
+    H.nfvel[k] = okr ? nf[1+k]/rho : 0.;
+    H.ngvel[k] = okp ? ng[1+k]/phi : 0.;
+    H.uf[k] = H.ufbar[k] + 0.5*H.af[k] - wphi*(H.ufbar[k]-H.ugbar[k] + 0.5*(H.af[k]-H.ag[k])) + 0.5*H.nfvel[k];
+    H.ug[k] = H.ugbar[k] + 0.5*H.ag[k] - wrho*(H.ugbar[k]-H.ufbar[k] + 0.5*(H.ag[k]-H.af[k])) + 0.5*H.ngvel[k];
+  }
+}
+
+// equilibrium_moments (LBM_binary.H:356-402): only modes 0..9 are non-zero.
+__device__ __forceinline__ void d_equilibrium(const DevParams& P, double rho, const double (&u)[3], double (&mEq)[10]) {
+  const double A00 = (rho*u[0]*u[0])/2./P.cs4;
+  const double A01 = (rho*u[0]*u[1])/2./P.cs4;
+  const double A02 = (rho*u[0]*u[2])/2./P.cs4;
+  const double A11 = (rho*u[1]*u[1])/2./P.cs4;
+  const double A12 = (rho*u[1]*u[2])/2./P.cs4;
+  const double A22 = (rho*u[2]*u[2])/2./P.cs4;
+  const double tr = A00 + A11 + A22;
+  mEq[0] = rho*1.;
+  mEq[1] = P.coefC_cs2*(rho*u[0]);
+  mEq[2] = P.coefC_cs2*(rho*u[1]);
+  mEq[3] = P.coefC_cs2*(rho*u[2]);
+  mEq[4] = P.two_cs4*tr;
+  mEq[5] = P.six_cs4*A00 - P.two_cs4*tr;
+  mEq[6] = P.two_cs4*(A11 - A22);
+  mEq[7] = P.cs4*(A01 + A01);
+  mEq[8] = P.cs4*(A12 + A12);
+  mEq[9] = P.cs4*(A02 + A02);
+}
+
+// phi_moments (LBM_binary.H:404-449)
+__device__ __forceinline__ void d_force_moments(const DevParams& P, double rho, const double (&u)[3], const double (&a)[3], double (&mPhi)[10]) {
+  const double coefAC = rho*P.coefC;
+  double ru[3] = { rho*u[0], rho*u[1], rho*u[2] };
+  const double A00 = a[0]*ru[0]/P.cs4, A01 = a[0]*ru[1]/P.cs4, A02 = a[0]*ru[2]/P.cs4;
+  const double A10 = a[1]*ru[0]/P.cs4, A11 = a[1]*ru[1]/P.cs4, A12 = a[1]*ru[2]/P.cs4;
+  const double A20 = a[2]*ru[0]/P.cs4, A21 = a[2]*ru[1]/P.cs4, A22 = a[2]*ru[2]/P.cs4;
+  const double tr = A00 + A11 + A22;
+  mPhi[0] = P.modifactor*(rho*0.);
+  mPhi[1] = P.modifactor*coefAC*P.cs2*a[0];
+  mPhi[2] = P.modifactor*coefAC*P.cs2*a[1];
+  mPhi[3] = P.modifactor*coefAC*P.cs2*a[2];
+  mPhi[4] = P.mod2*P.cs4*tr;
+  mPhi[5] = P.modifactor*(P.six_cs4*A00 - P.two_cs4*tr);
+  mPhi[6] = P.mod2*P.cs4*(A11 - A22);
+  mPhi[7] = P.modifactor*P.cs4*(A01 + A10);
+  mPhi[8] = P.modifactor*P.cs4*(A12 + A21);
+  mPhi[9] = P.modifactor*P.cs4*(A02 + A20);
+}
+
+// collide (LBM_binary.H:451-516): fs,gs are replaced by the post-collision populations.
+// NOISE=false drops the noise terms (they are exactly +-0 when kBT == 0).
+template <bool NOISE>
+__device__ __forceinline__ void d_collide(const DevParams& P, double (&fs)[Q], double (&gs)[Q],
+                                          double rho, double phi, const SiteHydro& H,
+                                          const double (&fn)[Q], const double (&gn)[Q]) {
+  double v_b[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v_b[k] = (rho*H.uf[k] + phi*H.ug[k])/(rho + phi);
+  {
+    double m[Q], mEq[10], mPhi[10];
+    d_moments(fs, m);
+    d_equilibrium(P, rho, v_b, mEq);
+    d_force_moments(P, rho, H.uf, H.af, mPhi);
+#pragma unroll
+    for (int a = 0; a < 10; ++a) {
+      double R = P.inv_tau_f_bar*(mEq[a] - m[a]) + mPhi[a];
+      if (NOISE) R = R + fn[a];
+      m[a] = m[a] + R;
+    }
+#pragma unroll
+    for (int a = 10; a < Q; ++a) {
+      double R = P.inv_tau_f_bar*(0. - m[a]) + 0.;
+      if (NOISE) R = R + fn[a];
+      m[a] = m[a] + R;
+    }
+    d_populations(m, fs);
+  }
+  {
+    double m[Q], mEq[10], mPhi[10];
+    d_moments(gs, m);
+    d_equilibrium(P, phi, v_b, mEq);
+    d_force_moments(P, phi, H.ug, H.ag, mPhi);
+#pragma unroll
+    for (int a = 0; a < 10; ++a) {
+      double R = P.inv_tau_g_bar*(mEq[a] - m[a]) + mPhi[a];
+      if (NOISE) R = R + gn[a];
+      m[a] = m[a] + R;
+    }
+#pragma unroll
+    for (int a = 10; a < Q; ++a) {
+      double R = P.inv_tau_g_bar*(0. - m[a]) + 0.;
+      if (NOISE) R = R + gn[a];
+      m[a] = m[a] + R;
+    }
+    d_populations(m, gs);
+  }
+}
+
+#endif  // BFLBM_SITE_H_

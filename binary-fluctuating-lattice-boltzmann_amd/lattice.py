@@ -1,0 +1,266 @@
+"""Host-side mirror of the reference's LBM operator surface (LBM_binary.H) for one z-slab.
+
+The method names, argument meaning and state semantics follow the reference's free
+functions so that tests read like the reference's own driver (main_run_job.cpp:269-339):
+
+    LBM_init_mixture / LBM_init_stripe(frac) / LBM_init_droplet(r) / LBM_init(f0, g0)
+    LBM_timestep()                       LBM_binary.H:545-594
+    LBM_hydrovars_density() -> hydrovsbar  :343-354
+    thermal_noise() -> fnoisevs, gnoisevs  :73-132
+    LBM_hydrovars() -> hydrovs             :298-313
+    update_com()                           LBM_hydrovs.H:26-60
+
+All arithmetic happens in the HIP library behind the C-ABI (include/bflbm.h); this file
+only moves numpy arrays in AMReX FAB layout (component slowest, x fastest) across it.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import Domain, Fab, Params, NVEL, NHYDRO, NHYDROBAR, check
+
+
+def default_params(**overrides):
+    """The reference's shipped globals (LBM_binary.H:17-30, LBM_d3q19.H:6-10)."""
+    p = Params()
+    _lib.load().bflbm_default_params(ctypes.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(f"unknown model parameter {k!r}")
+        setattr(p, k, v)
+    return p
+
+
+def make_fab(lo, hi, vlo=None, vhi=None):
+    """bflbm_fab for a host array allocated over cells lo..hi with valid region vlo..vhi."""
+    f = Fab()
+    vlo = lo if vlo is None else vlo
+    vhi = hi if vhi is None else vhi
+    for d in range(3):
+        f.lo[d], f.hi[d], f.vlo[d], f.vhi[d] = int(lo[d]), int(hi[d]), int(vlo[d]), int(vhi[d])
+    return f
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _check_array(a, ncomp, shape3, name):
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags.c_contiguous:
+        raise TypeError(f"{name}: need a C-contiguous float64 numpy array")
+    if a.shape != (ncomp,) + tuple(shape3):
+        raise ValueError(f"{name}: shape {a.shape}, expected {(ncomp,) + tuple(shape3)}")
+
+
+class BinaryLBM:
+    """One z-slab [z0, z1) of a periodic nx*ny*nz D3Q19 binary-fluid lattice on one GPU."""
+
+    def __init__(self, nx, ny=None, nz=None, params=None, z0=0, z1=None, rank=0, nranks=1,
+                 device=0, schedule=None, stream=None):
+        self.lib = _lib.load()
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        z1 = nz if z1 is None else z1
+        self.n = (int(nx), int(ny), int(nz))
+        self.z0, self.z1 = int(z0), int(z1)
+        self.nzl = self.z1 - self.z0
+        self.rank, self.nranks = int(rank), int(nranks)
+        self.params = params if params is not None else default_params()
+        dom = Domain()
+        dom.n[0], dom.n[1], dom.n[2] = self.n
+        dom.z0, dom.z1, dom.rank, dom.nranks, dom.device = self.z0, self.z1, self.rank, self.nranks, int(device)
+        h = ctypes.c_void_p()
+        check(self.lib.bflbm_create(ctypes.byref(self.params), ctypes.byref(dom), ctypes.byref(h)))
+        self._h = h
+        if stream is not None:
+            check(self.lib.bflbm_set_stream(self._h, ctypes.c_void_p(stream)))
+        if schedule is not None:
+            self.set_schedule(schedule)
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.bflbm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- configuration (the reference edits source-level globals) ---------------------------
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.params, k):
+                raise AttributeError(f"unknown model parameter {k!r}")
+            setattr(self.params, k, v)
+        check(self.lib.bflbm_set_params(self._h, ctypes.byref(self.params)))
+
+    def set_schedule(self, schedule):
+        code = {"two_pass": 0, "fused": 1}.get(schedule, schedule)
+        check(self.lib.bflbm_set_schedule(self._h, int(code)))
+
+    # -- shapes ----------------------------------------------------------------------------
+    @property
+    def slab_shape(self):
+        return (self.nzl, self.n[1], self.n[0])
+
+    def slab_fab(self):
+        """FAB descriptor of a ghost-free array covering exactly this slab."""
+        lo = (0, 0, self.z0)
+        hi = (self.n[0] - 1, self.n[1] - 1, self.z1 - 1)
+        return make_fab(lo, hi)
+
+    def _new(self, ncomp):
+        return np.empty((ncomp,) + self.slab_shape, dtype=np.float64)
+
+    # -- initial conditions ------------------------------------------------------------------
+    def LBM_init_mixture(self):
+        check(self.lib.bflbm_init_mixture(self._h))
+
+    def LBM_init_stripe(self, frac):
+        check(self.lib.bflbm_init_stripe(self._h, float(frac)))
+
+    def LBM_init_droplet(self, r):
+        check(self.lib.bflbm_init_droplet(self._h, float(r)))
+
+    def upload(self, f0, g0, fab=None):
+        """Stage populations of one box (mf.ParallelCopy(mf0), LBM_binary.H:643)."""
+        if fab is None:
+            _check_array(f0, NVEL, self.slab_shape, "f0")
+            _check_array(g0, NVEL, self.slab_shape, "g0")
+            fab = self.slab_fab()
+        check(self.lib.bflbm_upload_fg(self._h, _ptr(f0), _ptr(g0), ctypes.byref(fab)))
+
+    def commit_upload(self, reset_step_counter=True):
+        check(self.lib.bflbm_commit_upload(self._h, int(bool(reset_step_counter))))
+
+    def LBM_init(self, f0, g0, fab=None):
+        """Continue from given populations (LBM_binary.H:632-661); single slab only --
+        multi-slab callers use SlabLattice.LBM_init which exchanges the z faces."""
+        if self.nranks != 1:
+            raise _lib.BflbmError("BinaryLBM.LBM_init needs the slab driver when nranks > 1")
+        self.upload(f0, g0, fab)
+        self.commit_upload(True)
+
+    # -- time stepping ---------------------------------------------------------------------
+    def LBM_timestep(self, nsteps=1):
+        check(self.lib.bflbm_step(self._h, int(nsteps)))
+
+    def step_boundary(self):
+        check(self.lib.bflbm_step_boundary(self._h))
+
+    def step_interior(self):
+        check(self.lib.bflbm_step_interior(self._h))
+
+    def step_finish(self):
+        check(self.lib.bflbm_step_finish(self._h))
+
+    @property
+    def steps_done(self):
+        n = ctypes.c_longlong()
+        check(self.lib.bflbm_step_count(self._h, ctypes.byref(n)))
+        return n.value
+
+    # -- state and per-step fields -------------------------------------------------------------
+    def populations(self, f=None, g=None, fab=None):
+        """fold, gold valid cells (post-stream state of the last completed step)."""
+        if fab is None:
+            f = self._new(NVEL) if f is None else f
+            g = self._new(NVEL) if g is None else g
+            fab = self.slab_fab()
+        check(self.lib.bflbm_download_fg(self._h, _ptr(f), _ptr(g), ctypes.byref(fab)))
+        return f, g
+
+    def LBM_hydrovars_density(self, out=None, fab=None, ncomp=NHYDROBAR):
+        if fab is None:
+            out = self._new(ncomp) if out is None else out
+            fab = self.slab_fab()
+        check(self.lib.bflbm_get_hydrovsbar(self._h, _ptr(out), int(ncomp), ctypes.byref(fab)))
+        return out
+
+    def LBM_hydrovars(self, out=None, fab=None, ncomp=NHYDRO):
+        if fab is None:
+            out = self._new(ncomp) if out is None else out
+            fab = self.slab_fab()
+        check(self.lib.bflbm_get_hydrovs(self._h, _ptr(out), int(ncomp), ctypes.byref(fab)))
+        return out
+
+    def thermal_noise(self, fn=None, gn=None, fab=None):
+        if fab is None:
+            fn = self._new(NVEL) if fn is None else fn
+            gn = self._new(NVEL) if gn is None else gn
+            fab = self.slab_fab()
+        check(self.lib.bflbm_get_noise(self._h, _ptr(fn), _ptr(gn), ctypes.byref(fab)))
+        return fn, gn
+
+    def inject_noise(self, fn, gn, fab=None):
+        """Test hook: the next step's collision uses these noise moments."""
+        if fn is None:
+            check(self.lib.bflbm_inject_noise(self._h, None, None, None))
+            return
+        if fab is None:
+            _check_array(fn, NVEL, self.slab_shape, "fn")
+            _check_array(gn, NVEL, self.slab_shape, "gn")
+            fab = self.slab_fab()
+        check(self.lib.bflbm_inject_noise(self._h, _ptr(fn), _ptr(gn), ctypes.byref(fab)))
+
+    # -- reductions -------------------------------------------------------------------------
+    def com_sums(self):
+        s = (ctypes.c_double * 4)()
+        check(self.lib.bflbm_com_sums(self._h, s))
+        return np.array(list(s))
+
+    def update_com(self):
+        """Centre of mass of rho (LBM_hydrovs.H:26-60), single slab."""
+        s = self.com_sums()
+        return s[1:] / s[0]
+
+    def mass(self):
+        r, p = ctypes.c_double(), ctypes.c_double()
+        check(self.lib.bflbm_mass(self._h, ctypes.byref(r), ctypes.byref(p)))
+        return r.value, p.value
+
+    # -- halo exchange plumbing (used by slab.SlabLattice) ---------------------------------------
+    def halo_bytes(self, kind=_lib.HALO_STATE):
+        n = ctypes.c_size_t()
+        check(self.lib.bflbm_halo_bytes(self._h, int(kind), ctypes.byref(n)))
+        return n.value
+
+    def halo_pack(self, kind, side, device_ptr):
+        check(self.lib.bflbm_halo_pack(self._h, int(kind), int(side), ctypes.c_void_p(device_ptr)))
+
+    def halo_unpack(self, kind, side, device_ptr):
+        check(self.lib.bflbm_halo_unpack(self._h, int(kind), int(side), ctypes.c_void_p(device_ptr)))
+
+    # -- misc ------------------------------------------------------------------------------
+    def sync(self):
+        check(self.lib.bflbm_sync(self._h))
+
+    def timer_start(self):
+        check(self.lib.bflbm_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        check(self.lib.bflbm_timer_stop(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def device_bytes(self):
+        n = ctypes.c_size_t()
+        check(self.lib.bflbm_device_bytes(self._h, ctypes.byref(n)))
+        return n.value
+
+
+def rng_site_normals(seed, site, noise_index):
+    """Host evaluation of the project's Gaussian stream (36 values per site and index)."""
+    out = (ctypes.c_double * 36)()
+    check(_lib.load().bflbm_rng_site_normals(int(seed), int(site), int(noise_index), out))
+    return np.array(list(out))

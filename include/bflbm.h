@@ -1,0 +1,180 @@
+/*
+ * bflbm.h -- C-ABI of the MI355X-native D3Q19 binary fluctuating-LBM hot path.
+ *
+ * The reference (MDProject/Binary-Fluctuating-Lattice-Boltzmann) has no FFI layer:
+ * its operator surface is a set of C++ free functions over AMReX MultiFabs
+ * (LBM_binary.H).  Each entry point below names the reference interface it
+ * replaces.  The header adapter include/bflbm_amrex.H re-creates those C++
+ * signatures on top of this ABI; python binds it with ctypes.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure; the message is
+ *    available from bflbm_last_error() (the reference returns void and aborts,
+ *    LBM_binary.H:622 AMREX_GPU_ERROR_CHECK / Debug.H:141 exit).
+ *  - host arrays use the AMReX FAB layout: x fastest, then y, z, component
+ *    slowest, over a box [lo,hi] that may include ghost cells (bflbm_fab).
+ *  - one context = one z-slab [z0,z1) of a periodic nx*ny*nz lattice on one
+ *    GPU.  Work is enqueued on the context's HIP stream; call bflbm_sync()
+ *    (or synchronise the stream you supplied) before reading results.
+ *  - not re-entrant per context; one host thread per context.
+ */
+#ifndef BFLBM_H_
+#define BFLBM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFLBM_NVEL 19          /* nvel, LBM_d3q19.H:4 */
+#define BFLBM_NHYDRO 22        /* hydrovs components, main_run_job.cpp:147 */
+#define BFLBM_NHYDROBAR 9      /* hydrovsbar components actually defined, LBM_binary.H:329-339 */
+#define BFLBM_ABI_VERSION 1
+
+/* Mirrors the reference's process-wide model globals.
+ * tau_f,tau_g,alpha0,alpha1,kappa,seed: LBM_binary.H:17-30; kBT,cs2: LBM_d3q19.H:6-10;
+ * rho_lo,rho_hi: LBM_binary.H:25-26.  alpha1 is carried but unused (LBM_binary.H:256-257). */
+typedef struct bflbm_params {
+  double tau_f, tau_g;
+  double alpha0, alpha1;
+  double kappa;
+  double kBT;
+  double cs2;
+  double rho_lo, rho_hi;
+  uint64_t seed;
+} bflbm_params;
+
+/* Lattice and slab.  Replaces Geometry/BoxArray/DistributionMapping of
+ * main_run_job.cpp:136-143 for the path: periodic box, z-slab per GPU. */
+typedef struct bflbm_domain {
+  int n[3];       /* global lattice nx,ny,nz */
+  int z0, z1;     /* this context owns global planes z0 <= z < z1 */
+  int rank;       /* slab index 0..nranks-1 (ring neighbours rank+-1 mod nranks) */
+  int nranks;     /* 1: z wraps inside the context, no halo exchange needed */
+  int device;     /* HIP device ordinal */
+} bflbm_domain;
+
+/* A host array in AMReX FAB layout: allocated over cells lo..hi inclusive (global
+ * indices, ghost cells included, this fixes the strides); only the cells of the
+ * valid region vlo..vhi that lie inside the context's slab are read or written
+ * (MFIter::validbox semantics, e.g. LBM_binary.H:609). */
+typedef struct bflbm_fab {
+  int lo[3];
+  int hi[3];
+  int vlo[3];
+  int vhi[3];
+} bflbm_fab;
+
+typedef struct bflbm_ctx bflbm_ctx;
+
+/* Fill *p with the reference's shipped defaults (LBM_binary.H:17-30, LBM_d3q19.H:6-10). */
+void bflbm_default_params(bflbm_params* p);
+
+int bflbm_abi_version(void);
+const char* bflbm_last_error(void);
+
+/* Number of HIP devices visible (does not create a context). */
+int bflbm_device_count(int* n);
+
+/* Allocate the resident state (two A/B buffers of 2x19 populations + rho/phi). */
+int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out);
+int bflbm_destroy(bflbm_ctx* c);
+
+/* The reference edits its globals between runs (ReadMe.ipynb cells 1-3). */
+int bflbm_set_params(bflbm_ctx* c, const bflbm_params* p);
+int bflbm_get_params(const bflbm_ctx* c, bflbm_params* p);
+
+/* Use the caller's hipStream_t (e.g. torch's current stream) for all work. NULL = own stream. */
+int bflbm_set_stream(bflbm_ctx* c, void* hip_stream);
+
+/* Kernel schedule: 0 = two-pass (density pass + collide pass), 1 = fused plane-marching kernel. */
+int bflbm_set_schedule(bflbm_ctx* c, int schedule);
+
+/* LBM_init_mixture (LBM_binary.H:598-629), LBM_init_stripe(frac) (:664-695),
+ * LBM_init_droplet(r) (:699-742).  Resets the step counter to 0. */
+int bflbm_init_mixture(bflbm_ctx* c);
+int bflbm_init_stripe(bflbm_ctx* c, double frac);
+int bflbm_init_droplet(bflbm_ctx* c, double r);
+
+/* LBM_init from given populations (LBM_binary.H:632-661 / mf.ParallelCopy(mf0)):
+ * copy the cells of `box` that lie in the slab from host arrays f,g (19 comps each).
+ * Call once per box of a multi-box MultiFab, then bflbm_commit_upload(). */
+int bflbm_upload_fg(bflbm_ctx* c, const double* f, const double* g, const bflbm_fab* box);
+int bflbm_commit_upload(bflbm_ctx* c, int reset_step_counter);
+
+/* fold/gold valid cells after LBM_timestep (state t): write the slab's cells
+ * that lie inside `box` into f,g (ghost cells of the destination are not touched). */
+int bflbm_download_fg(bflbm_ctx* c, double* f, double* g, const bflbm_fab* box);
+
+/* LBM_timestep (LBM_binary.H:545-594) applied nsteps times.  For nranks > 1 the
+ * caller must run the halo exchange between steps (see bflbm_halo_*), so only
+ * nsteps == 1 is accepted there; python/ C++ drivers wrap this. */
+int bflbm_step(bflbm_ctx* c, int nsteps);
+int bflbm_step_count(const bflbm_ctx* c, long long* steps_done);
+
+/* One step of a slab (nranks > 1) split so that the +-z exchange overlaps the
+ * interior planes.  Precondition: the resident state has valid halo planes.
+ *   bflbm_step_boundary  -> the two outermost plane pairs of the slab
+ *   bflbm_halo_pack(BFLBM_HALO_NEXT, side, buf) for side 0,1; start the exchange
+ *   bflbm_step_interior  -> all other planes (overlaps the exchange)
+ *   wait; bflbm_halo_unpack(BFLBM_HALO_NEXT, side, buf)
+ *   bflbm_step_finish    -> swap A/B buffers, advance the step counter
+ * With nranks == 1 these also work (halo calls are then not needed). */
+int bflbm_step_boundary(bflbm_ctx* c);
+int bflbm_step_interior(bflbm_ctx* c);
+int bflbm_step_finish(bflbm_ctx* c);
+
+/* Halo exchange support (replaces the +-z part of fold/gold/hydrovs FillBoundary,
+ * LBM_binary.H:553-555; x,y wrap inside the slab).  side 0 = low-z face, 1 = high-z
+ * face.  pack: gather what the neighbour on that side needs into a contiguous
+ * device buffer; unpack: store what was received FROM the neighbour on that side.
+ * kind selects the buffer and the plane set. */
+#define BFLBM_HALO_STATE 0   /* resident post-collision state: 38 component-planes per side */
+#define BFLBM_HALO_NEXT 1    /* same set, on the buffer the open step is writing */
+#define BFLBM_HALO_UPLOAD 2  /* uploaded populations before bflbm_commit_upload: 38 comps x 1 plane */
+int bflbm_halo_bytes(const bflbm_ctx* c, int kind, size_t* bytes_per_side);
+int bflbm_halo_pack(bflbm_ctx* c, int kind, int side, void* device_buf);
+int bflbm_halo_unpack(bflbm_ctx* c, int kind, int side, const void* device_buf);
+
+/* Materialise the per-step fields the reference keeps in MultiFabs, for the state
+ * after the last completed step:
+ *   hydrovsbar comps 0..8  (LBM_hydrovars_density, LBM_binary.H:315-354)
+ *   fnoisevs/gnoisevs      (thermal_noise, :73-132)
+ *   hydrovs comps 0..ncomp-1 <= 22 (LBM_hydrovars, :196-313; legacy drivers pass 15)
+ * Each destination is a host FAB of `box` with the stated number of components;
+ * NULL skips that field. */
+int bflbm_get_hydrovsbar(bflbm_ctx* c, double* dst, int ncomp, const bflbm_fab* box);
+int bflbm_get_hydrovs(bflbm_ctx* c, double* dst, int ncomp, const bflbm_fab* box);
+int bflbm_get_noise(bflbm_ctx* c, double* fnoise, double* gnoise, const bflbm_fab* box);
+
+/* Test hook: feed the collision of the NEXT step with these noise moments instead of
+ * the built-in generator (the reference's RNG stream is not reproducible).
+ * Pass NULL,NULL to return to the generator. */
+int bflbm_inject_noise(bflbm_ctx* c, const double* fnoise, const double* gnoise, const bflbm_fab* box);
+
+/* update_com (LBM_hydrovs.H:26-60) over this slab: sums of rho, rho*i, rho*j, rho*k
+ * (4 doubles; the caller all-reduces across slabs and divides). */
+int bflbm_com_sums(bflbm_ctx* c, double sums[4]);
+
+/* Total of rho and phi over the slab (PrintMassConservation, Debug.H:232-249). */
+int bflbm_mass(bflbm_ctx* c, double* rho_sum, double* phi_sum);
+
+int bflbm_sync(bflbm_ctx* c);
+
+/* hipEvent timing on the context's stream: start, run steps, stop -> milliseconds. */
+int bflbm_timer_start(bflbm_ctx* c);
+int bflbm_timer_stop(bflbm_ctx* c, float* ms);
+
+/* Host-side evaluation of the project's counter-based Gaussian stream (the HIP
+ * kernels use the same code); 36 values, 33 consumed per site and noise index. */
+int bflbm_rng_site_normals(uint64_t seed, uint64_t site, uint32_t noise_index, double* out36);
+
+/* Device bytes held by the context. */
+int bflbm_device_bytes(const bflbm_ctx* c, size_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFLBM_H_ */

@@ -1,0 +1,247 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): bit-exact site indexing/streaming; moments within 1e-12
+relative at zero noise.  The HIP library is built with FMA contraction off and keeps the
+reference's operation order, so we assert the stronger property: every double identical.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCHEDULES = ["two_pass"]
+
+
+def _same(a, b, what):
+    if not np.array_equal(a, b):
+        d = np.abs(a - b)
+        raise AssertionError(f"{what}: {np.count_nonzero(a != b)} of {a.size} doubles differ, max abs {d.max():.3e}")
+
+
+def _run_pair(pkg, ob, dims, init, steps, schedule, **par):
+    nx, ny, nz = dims
+    lbm = pkg.BinaryLBM(nx, ny, nz, params=pkg.default_params(**par), schedule=schedule)
+    ref = ob.OracleLattice(nx, ny, nz, params=ob.default_params(**par))
+    getattr(lbm, "LBM_init_" + init[0])(*init[1:])
+    getattr(ref, "init_" + init[0])(*init[1:])
+    return lbm, ref
+
+
+@pytest.mark.parametrize("schedule", SCHEDULES)
+@pytest.mark.parametrize("dims,init", [
+    ((8, 8, 8), ("stripe", 0.5)),
+    ((16, 16, 16), ("droplet", 0.3)),
+    ((12, 12, 12), ("mixture",)),
+    ((6, 6, 6), ("stripe", 0.5)),          # main_test.cpp:104-117 smoke size
+    ((8, 32, 16), ("stripe", 0.5)),        # anisotropic box like the flat-interface run (8x256x64)
+    ((5, 7, 9), ("droplet", 0.25)),        # odd, ragged sizes
+    ((64, 4, 4), ("droplet", 0.2)),        # Debug.ipynb 64x4x4 box
+])
+def test_init_matches_oracle(pkg, ob, dims, init, schedule):
+    lbm, ref = _run_pair(pkg, ob, dims, init, 0, schedule)
+    f, g = lbm.populations()
+    _same(f, ref.f, "f after init")
+    _same(g, ref.g, "g after init")
+    _same(lbm.LBM_hydrovars_density(), ref.hbar[:9], "hydrovsbar after init")
+    _same(lbm.LBM_hydrovars(), ref.h, "hydrovs after init")
+    lbm.close()
+
+
+@pytest.mark.parametrize("schedule", SCHEDULES)
+@pytest.mark.parametrize("dims,init,steps", [
+    ((8, 8, 8), ("stripe", 0.5), 10),
+    ((16, 16, 16), ("droplet", 0.3), 10),
+    ((12, 12, 12), ("mixture",), 3),
+    ((6, 6, 6), ("stripe", 0.5), 5),
+    ((5, 7, 9), ("droplet", 0.25), 7),
+    ((8, 32, 16), ("stripe", 0.5), 20),
+    ((16, 16, 16), ("stripe", 0.5), 100),
+])
+def test_zero_noise_steps_bit_exact(pkg, ob, dims, init, steps, schedule):
+    lbm, ref = _run_pair(pkg, ob, dims, init, steps, schedule)
+    lbm.LBM_timestep(steps)
+    for _ in range(steps):
+        ref.timestep()
+    f, g = lbm.populations()
+    _same(f, ref.f, f"fold after {steps} steps")
+    _same(g, ref.g, f"gold after {steps} steps")
+    _same(lbm.LBM_hydrovars_density(), ref.hbar[:9], "hydrovsbar")
+    _same(lbm.LBM_hydrovars(), ref.h, "hydrovs")
+    assert lbm.steps_done == steps
+    lbm.close()
+
+
+def test_survey_pins_on_gpu(pkg):
+    """The three reference outputs recorded in SURVEY.md 8c (8^3 stripe, 10 steps)."""
+    lbm = pkg.BinaryLBM(8, 8, 8)
+    lbm.LBM_init_stripe(0.5)
+    lbm.LBM_timestep(10)
+    hb = lbm.LBM_hydrovars_density()
+    h = lbm.LBM_hydrovars()
+    assert hb[0, 4, 0, 0] == float("1.0185845986909126")
+    assert h[4, 2, 0, 0] == float("0.048022250265876899")
+    tot = 0.0
+    for v in h[5].ravel():
+        tot += v
+    assert tot == float("511.99999999999886")
+    lbm.close()
+
+
+@pytest.mark.parametrize("par", [dict(alpha0=1.5, rho_hi=3.0), dict(tau_f=1.0, tau_g=1.0, alpha0=0.0),
+                                 dict(tau_f=0.8, tau_g=0.6, alpha0=2.5, kappa=3.0, rho_lo=0.1)])
+def test_other_parameter_sets(pkg, ob, par):
+    """Notebook parameter sets (Surface_Tension: alpha0=1.5, rho_hi=3; NoiseCovariance: tau=1)."""
+    lbm, ref = _run_pair(pkg, ob, (12, 12, 12), ("droplet", 0.3), 5, "two_pass", **par)
+    lbm.LBM_timestep(5)
+    for _ in range(5):
+        ref.timestep()
+    f, g = lbm.populations()
+    _same(f, ref.f, "f")
+    _same(g, ref.g, "g")
+    _same(lbm.LBM_hydrovars(), ref.h, "hydrovs")
+    lbm.close()
+
+
+def test_upload_download_roundtrip_and_continue(pkg, ob):
+    """LBM_init from given populations (LBM_binary.H:632-661), then keep stepping."""
+    rng = np.random.default_rng(7)
+    n = (10, 6, 8)
+    ref = ob.OracleLattice(*n)
+    ref.init_droplet(0.3)
+    f0 = ref.f * (1.0 + 0.01 * rng.standard_normal(ref.f.shape))
+    g0 = ref.g * (1.0 + 0.01 * rng.standard_normal(ref.g.shape))
+    ref.init_from(f0, g0)
+    lbm = pkg.BinaryLBM(*n)
+    lbm.LBM_init(f0.copy(), g0.copy())
+    f, g = lbm.populations()
+    _same(f, f0, "download(upload(f))")
+    _same(g, g0, "download(upload(g))")
+    _same(lbm.LBM_hydrovars(), ref.h, "hydrovs of uploaded state")
+    lbm.LBM_timestep(4)
+    for _ in range(4):
+        ref.timestep()
+    f, g = lbm.populations()
+    _same(f, ref.f, "f after continue")
+    _same(g, ref.g, "g after continue")
+    lbm.close()
+
+
+def test_multibox_ghosted_fabs(pkg, ob):
+    """The reference's default decomposition: 8 boxes of nx/2, nghost=2 (main_run_job.cpp:140-145).
+    Upload box by box from ghost-grown FABs, download into ghost-grown FABs, ghosts untouched."""
+    n = 8
+    ng = 2
+    ref = ob.OracleLattice(n, n, n)
+    ref.init_droplet(0.3)
+    lbm = pkg.BinaryLBM(n, n, n)
+    boxes = [((i * 4, j * 4, k * 4), (i * 4 + 3, j * 4 + 3, k * 4 + 3)) for k in range(2) for j in range(2) for i in range(2)]
+    fabs = []
+    for lo, hi in boxes:
+        glo = tuple(a - ng for a in lo)
+        ghi = tuple(a + ng for a in hi)
+        shp = (19, ghi[2] - glo[2] + 1, ghi[1] - glo[1] + 1, ghi[0] - glo[0] + 1)
+        ff = np.full(shp, np.nan)
+        gg = np.full(shp, np.nan)
+        sl = (slice(None), slice(ng, ng + 4), slice(ng, ng + 4), slice(ng, ng + 4))
+        src = (slice(None), slice(lo[2], hi[2] + 1), slice(lo[1], hi[1] + 1), slice(lo[0], hi[0] + 1))
+        ff[sl] = ref.f[src]
+        gg[sl] = ref.g[src]
+        fab = pkg.make_fab(glo, ghi, lo, hi)
+        lbm.upload(ff, gg, fab)
+        fabs.append((fab, sl, src))
+    lbm.commit_upload()
+    lbm.LBM_timestep(3)
+    for _ in range(3):
+        ref.timestep()
+    for fab, sl, src in fabs:
+        shp = (19, 8, 8, 8)
+        ff = np.full(shp, -7.0)
+        gg = np.full(shp, -7.0)
+        lbm.populations(ff, gg, fab)
+        _same(ff[sl], ref.f[src], "box f")
+        _same(gg[sl], ref.g[src], "box g")
+        mask = np.ones(shp, bool)
+        mask[sl] = False
+        assert np.all(ff[mask] == -7.0) and np.all(gg[mask] == -7.0), "ghost cells were written"
+        hh = np.full((22, 8, 8, 8), -7.0)
+        lbm.LBM_hydrovars(hh, fab)
+        _same(hh[(slice(None),) + sl[1:]], ref.h[(slice(None),) + src[1:]], "box hydrovs")
+    lbm.close()
+
+
+def test_legacy_15_component_hydrovs(pkg, ob):
+    """main_driver.cpp:165 allocates nhydro=15: never write past hydrovs.nComp()."""
+    lbm, ref = _run_pair(pkg, ob, (8, 8, 8), ("stripe", 0.5), 0, "two_pass")
+    out = np.full((16, 8, 8, 8), 123.0)
+    lbm.LBM_hydrovars(out[:15], ncomp=15)
+    _same(out[:15], ref.h[:15], "15-component hydrovs")
+    assert np.all(out[15] == 123.0)
+    lbm.close()
+
+
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_injected_noise_step_bit_exact(pkg, ob, schedule):
+    """Feed both implementations the same noise moments (exact noise parity is only
+    possible with injected arrays because amrex::RandomNormal is not reproducible)."""
+    rng = np.random.default_rng(11)
+    n = (8, 10, 12)
+    par = dict(kBT=1e-5, alpha0=1.0)
+    lbm, ref = _run_pair(pkg, ob, n, ("droplet", 0.3), 0, schedule, **par)
+    for s in range(3):
+        fn = 1e-3 * rng.standard_normal(ref.f.shape)
+        gn = 1e-3 * rng.standard_normal(ref.f.shape)
+        fn[0] = 0.0
+        gn[0] = 0.0
+        gn[1:4] = -fn[1:4]
+        lbm.inject_noise(fn, gn)
+        _same(lbm.LBM_hydrovars(), _hydro_with(ref, fn, gn), f"hydrovs with injected noise, step {s}")
+        lbm.LBM_timestep(1)
+        ref.timestep_injected(fn, gn)
+        f, g = lbm.populations()
+        _same(f, ref.f, f"f after injected step {s}")
+        _same(g, ref.g, f"g after injected step {s}")
+    lbm.close()
+
+
+def _hydro_with(ref, fn, gn):
+    import ctypes
+    import oracle_binding as ob
+    nx, ny, nz = ref.n
+    h = np.empty_like(ref.h)
+    ob.lib().orc_hydrovars(ctypes.byref(ref.p), nx, ny, nz, ob._p(ref.f), ob._p(ref.g), ob._p(ref.hbar),
+                           ob._p(np.ascontiguousarray(fn)), ob._p(np.ascontiguousarray(gn)), ob._p(h))
+    return h
+
+
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_generated_noise_matches_oracle_stream(pkg, ob, schedule):
+    """Same seed, same counter-based stream: noise moments and the noisy trajectory are bit-identical
+    (binary32 Box-Muller built from IEEE + - * / sqrt only; sqrt(double) correctly rounded)."""
+    n = (8, 8, 8)
+    par = dict(kBT=1e-5, alpha0=0.0, tau_f=1.0, tau_g=1.0, seed=2024)   # NoiseCovariance.ipynb parameters
+    lbm, ref = _run_pair(pkg, ob, n, ("mixture",), 0, schedule, **par)
+    fn, gn = lbm.thermal_noise()
+    _same(fn, ref.fn, "fnoise at init")
+    _same(gn, ref.gn, "gnoise at init")
+    assert np.all(fn[0] == 0) and np.all(gn[0] == 0)
+    assert np.array_equal(gn[1:4], -fn[1:4])
+    lbm.LBM_timestep(5)
+    for _ in range(5):
+        ref.timestep()
+    f, g = lbm.populations()
+    _same(f, ref.f, "f after 5 noisy steps")
+    _same(g, ref.g, "g after 5 noisy steps")
+    fn, gn = lbm.thermal_noise()
+    _same(fn, ref.fn, "fnoise after 5 steps")
+    _same(lbm.LBM_hydrovars(), ref.h, "hydrovs after 5 noisy steps")
+    lbm.close()
+
+
+def test_mass_and_com(pkg, ob):
+    lbm, ref = _run_pair(pkg, ob, (12, 10, 8), ("droplet", 0.3), 0, "two_pass")
+    lbm.LBM_timestep(2)
+    ref.timestep(); ref.timestep()
+    r, p = lbm.mass()
+    assert abs(r - ref.hbar[0].sum()) < 1e-9 and abs(p - ref.hbar[1].sum()) < 1e-9
+    np.testing.assert_allclose(lbm.update_com(), ref.com(), rtol=1e-12)
+    lbm.close()
