@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MLUPS of the D3Q19x2 binary fluctuating-LBM step on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--noise] [--schedule fused|two_pass]
+
+A "step" is one LBM_timestep-equivalent (stream + densities + noise + projection + collide,
+LBM_binary.H:545-594) over the whole lattice.  N=1: BASELINE.json configs[1], a 256^3 periodic
+box at zero noise (stripe init).  N>1: weak scaling, every GPU owns a 256x256x256 z-slab of a
+256x256x(256 N) box, +-z planes exchanged over RCCL and overlapped with the interior planes.
+Populations are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BYTES_PER_LUP = 608.0          # 2 fluids x 19 populations x 8 B x (1 read + 1 write), BASELINE.md section 3
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline():
+    """Time the CPU oracle (restated reference path, 1 thread) on a bounded sample."""
+    import oracle_binding as ob
+    n, steps = 64, 12
+    secs, _ = ob.bench(n, n, n, steps)
+    return {"value": round(n ** 3 * steps / secs / 1e6, 4), "unit": "MLUPS", "cores": 1, "kind": "port",
+            "sample": f"{n}^3 stripe, kBT=0, {steps} steps after 1 warm-up, oracle/bflbm_oracle.c -O3 -ffp-contract=off, 1 thread",
+            "host_cores": os.cpu_count()}
+
+
+def load_traffic(workload, schedule):
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        return t.get(f"{workload}|{schedule}")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=256, help="cubic box edge at N=1 / slab edge per GPU")
+    ap.add_argument("--noise", action="store_true", help="kBT=1e-5 (configs[2]) instead of zero noise")
+    ap.add_argument("--init", default="stripe", choices=["stripe", "droplet", "mixture"])
+    ap.add_argument("--schedule", default=os.environ.get("BFLBM_SCHEDULE", "two_pass"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    S = a.size
+    nx, ny, nz = S, S, S * world
+    par = dict(kBT=1e-5, alpha0=0.0) if a.noise else {}
+    params = pkg.default_params(**par)
+
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        lat = pkg.SlabLattice(nx, ny, nz, params=params, schedule=a.schedule)
+        eng = lat.engine
+
+        def barrier():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        lat = pkg.BinaryLBM(nx, ny, nz, params=params, device=local_rank, schedule=a.schedule)
+        eng = lat
+
+        def barrier():
+            eng.sync()
+
+    getattr(lat, "LBM_init_" + a.init)(*([0.5] if a.init == "stripe" else [0.2] if a.init == "droplet" else []))
+    lat.LBM_timestep(a.warmup)
+    barrier()
+    eng.timer_start()
+    t0 = time.perf_counter()
+    lat.LBM_timestep(a.steps)
+    dev_ms = eng.timer_stop()              # hipEvents on the stream the kernels run on
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = t.tolist()
+    rho_sum, phi_sum = lat.mass()
+
+    if rank == 0:
+        sites = float(nx) * ny * nz
+        mlups = sites * a.steps / wall / 1e6
+        ms_step = wall / a.steps * 1e3
+        per_gpu_sites = sites / world
+        kern_ms = dev_ms / a.steps
+        achieved = per_gpu_sites * BYTES_PER_LUP / (kern_ms * 1e-3) / 1e9
+        workload = f"{nx}x{ny}x{nz} periodic, {a.init} init, " + ("kBT=1e-5 alpha0=0" if a.noise else "zero noise")
+        out = {
+            "metric": "MLUPS (million lattice-site updates/sec) D3Q19x2", "value": round(mlups, 1), "unit": "MLUPS",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "schedule": a.schedule, "slab_per_gpu": f"{nx}x{ny}x{nz // world}",
+                       "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
+                       "mass_check": [rho_sum, phi_sum]},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": load_traffic(f"{nx}x{ny}x{nz}", a.schedule),
+                         "kernel": "all kernels of one step (hipEvent time / steps)",
+                         "algorithmic_bytes_per_launch": per_gpu_sites * BYTES_PER_LUP,
+                         "avg_launch_ms": round(kern_ms, 4)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        lat.close()
+        dist.destroy_process_group()
+    else:
+        lat.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbflbm.so")
+LIB_PATH = os.environ.get("BFLBM_LIB", os.path.join(_HERE, "csrc", "libbflbm.so"))   # override only for A/B kernel builds
 
 NVEL = 19
 NHYDRO = 22

@@ -1,7 +1,221 @@
-// bflbm_fused.h -- fused plane-marching kernel (schedule 1).  Placeholder until implemented.
+// bflbm_fused.h -- fused plane-marching collide-and-stream kernel (schedule 1).
+//
+// One HBM pass per LBM_timestep: read 38 populations, write 38 populations per site.
+//
+// Each workgroup owns a TX x TY tile in (x,y) and marches through a chunk of planes along z.
+// At march position q every thread
+//   1. pulls the 38 populations of its site in plane q (f_i(x) = S_i(x - c_i), coalesced along x)
+//      and keeps them in registers;
+//   2. sums them in the reference's order -> rho,phi of plane q (LBM_binary.H:320-330) into an
+//      LDS ring slot; the lanes of the tile additionally pull-and-sum the one-site ring around
+//      the tile (those loads are L2 hits: the neighbouring tile's workgroup streams the same
+//      lines), so the slot covers (TX+2) x (TY+2) sites;
+//   3. after one barrier, collides plane q-1 from the registers kept at the previous position,
+//      with the 18-neighbour gradient stencil (LBM_binary.H:134-150) served from the LDS slots
+//      of planes q-2, q-1, q, and writes the post-collision populations of plane q-1.
+// The slab is split into chunks of planes so that the grid has >> 256 workgroups; a chunk of
+// L planes pulls L+2 planes (the two extra only for their densities).
+//
+// The arithmetic is the same device functions as the two-pass schedule (bflbm_site.h), so both
+// schedules and the CPU oracle agree bit for bit.
 #ifndef BFLBM_FUSED_H_
 #define BFLBM_FUSED_H_
+
 #include "bflbm_kernels.h"
-static inline int fused_launch(const double*, double*, const double*, const double*, const Geo&, const DevParams&,
-                               int, int, uint32_t, int, hipStream_t) { return 1; }
+
+struct FusedGrid {
+  int ntx, nty;        // tiles in x and y
+  int pa, pb;          // storage planes [pa,pb) to advance
+  int lz;              // planes per chunk
+  int nchunks;
+  int ncols;           // ntx*nty
+  int total;           // ncols*nchunks workgroups
+  int per_xcd;         // ceil(total/8)
+};
+
+// Workgroup -> (column, chunk).  Workgroups b and b+8 share an XCD (round-robin dispatch), so give
+// each XCD a contiguous band of tile columns: halo lines are then shared through that XCD's L2.
+// Placement only affects speed.
+__device__ __forceinline__ bool fused_map(const FusedGrid& F, int b, int& col, int& chunk) {
+  const int xcd = b & 7, j = b >> 3;
+  const int w = xcd * F.per_xcd + j;             // position in the XCD-major work list
+  if (j >= F.per_xcd || w >= F.total) return false;
+  // inside the list: chunk-major over groups of columns so that concurrently resident workgroups
+  // of one XCD are neighbouring columns of the same chunk
+  col = w % F.ncols;
+  chunk = w / F.ncols;
+  // interleave: consecutive w within an XCD walk columns first
+  return true;
+}
+
+template <int TX, int TY, int MODE>   // MODE 0: no noise, 1: generated noise, 2: injected noise
+__global__ void __launch_bounds__(TX*TY, 2)
+k_fused(const double* __restrict__ S, double* __restrict__ D,
+        const double* __restrict__ injf, const double* __restrict__ injg,
+        Geo G, DevParams P, FusedGrid F, uint32_t noise_index) {
+  constexpr int LW = TX + 2;                     // LDS row length
+  constexpr int LSZ = (TX + 2) * (TY + 2);
+  __shared__ double rp[4][2][LSZ];               // ring of 4 planes x {rho,phi}
+
+  int col, chunk;
+  const bool live = fused_map(F, (int)blockIdx.x, col, chunk);
+  if (!live) return;                             // whole workgroup leaves together
+  const int tix = col % F.ntx, tiy = col / F.ntx;
+  const int x0 = tix * TX, y0 = tiy * TY;
+  const int aw = min(TX, G.nx - x0), ah = min(TY, G.ny - y0);   // active extent of this tile
+  const int tid = threadIdx.x;
+  const int tx = tid % TX, ty = tid / TX;
+  const bool own = (tx < aw) && (ty < ah);
+
+  // ---- per-thread addressing, fixed for the whole march
+  auto wrapx = [&](int v) { return v < 0 ? v + G.nx : (v >= G.nx ? v - G.nx : v); };
+  auto wrapy = [&](int v) { return v < 0 ? v + G.ny : (v >= G.ny ? v - G.ny : v); };
+  const int x = own ? x0 + tx : x0, y = own ? y0 + ty : y0;
+  const int xo[3] = { wrapx(x - 1), x, wrapx(x + 1) };
+  const int yo[3] = { wrapy(y - 1) * G.nx, y * G.nx, wrapy(y + 1) * G.nx };
+
+  // halo ring of the active rectangle: 2*(aw+2) + 2*ah sites, two half-tasks (f, g) each,
+  // spread evenly over the waves (lanes 0..nper-1 of each wave)
+  const int nring = 2 * (aw + 2) + 2 * ah;
+  const int ntask = 2 * nring;
+  constexpr int NW = TX * TY / 64;
+  const int nper = (ntask + NW - 1) / NW;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int task = (lane < nper) ? wv * nper + lane : -1;
+  const bool has_task = task >= 0 && task < ntask;
+  int hfl = 0, hlx = 0, hly = 0;                 // fluid, LDS coordinates of the ring site
+  if (has_task) {
+    hfl = task / nring;
+    int r = task - hfl * nring;
+    if (r < aw + 2) { hlx = r; hly = 0; }
+    else if (r < 2 * (aw + 2)) { hlx = r - (aw + 2); hly = ah + 1; }
+    else if (r < 2 * (aw + 2) + ah) { hlx = 0; hly = r - 2 * (aw + 2) + 1; }
+    else { hlx = aw + 1; hly = r - 2 * (aw + 2) - ah + 1; }
+  }
+  const int hx = wrapx(x0 + hlx - 1);            // in [-1, nx]: one wrap suffices
+  const int hy = wrapy(y0 + hly - 1);
+  const int hxo[3] = { wrapx(hx - 1), hx, wrapx(hx + 1) };
+  const int hyo[3] = { wrapy(hy - 1) * G.nx, hy * G.nx, wrapy(hy + 1) * G.nx };
+  const long long hbase = (long long)hfl * Q * G.vol;
+
+  const int lown = (ty + 1) * LW + (tx + 1);
+  const int lhalo = hly * LW + hlx;
+
+  // ---- chunk of planes
+  const int qa = F.pa + chunk * F.lz;
+  const int qb = min(F.pb, qa + F.lz);
+  auto wrapp = [&](int q) {
+    if (!G.zwrap) return q;
+    return q < 0 ? q + G.nzs : (q >= G.nzs ? q - G.nzs : q);
+  };
+
+  double pf[Q], pg[Q];                           // pulled populations of the previous plane
+#pragma unroll
+  for (int i = 0; i < Q; ++i) { pf[i] = 0.; pg[i] = 0.; }
+
+  int it = 0;
+  for (int q = qa - 1; q <= qb; ++q, ++it) {
+    const int slot = it & 3;
+    const long long pl[3] = { (long long)wrapp(q - 1) * G.plane, (long long)wrapp(q) * G.plane, (long long)wrapp(q + 1) * G.plane };
+    // 1. pull plane q
+    double cf[Q], cg[Q];
+    if (own) {
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const long long o = pl[1 - Vel::cz[i]] + yo[1 - Vel::cy[i]] + xo[1 - Vel::cx[i]];
+        cf[i] = S[(long long)i * G.vol + o];
+        cg[i] = S[(long long)(i + Q) * G.vol + o];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < Q; ++i) { cf[i] = 0.; cg[i] = 0.; }
+    }
+    double hsum = 0.0;
+    if (has_task) {
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const long long o = pl[1 - Vel::cz[i]] + hyo[1 - Vel::cy[i]] + hxo[1 - Vel::cx[i]];
+        hsum += S[hbase + (long long)i * G.vol + o];
+      }
+    }
+    // 2. densities of plane q into the ring slot
+    const double rq = d_density(cf), phq = d_density(cg);
+    if (own) { rp[slot][0][lown] = rq; rp[slot][1][lown] = phq; }
+    if (has_task) rp[slot][hfl][lhalo] = hsum;
+    __syncthreads();
+    // 3. collide plane q-1 (registers pf,pg; slots it-2, it-1, it)
+    if (q - 1 >= qa && q - 1 < qb && own) {
+      const int sl[3] = { (it - 2) & 3, (it - 1) & 3, it & 3 };
+      const double r = rp[sl[1]][0][lown], ph = rp[sl[1]][1][lown];
+      double nb[Q], grad_rho[3], grad_phi[3];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) nb[i] = rp[sl[1 + Vel::cz[i]]][0][lown + Vel::cy[i] * LW + Vel::cx[i]];
+      d_gradient(P, nb, grad_rho);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) nb[i] = rp[sl[1 + Vel::cz[i]]][1][lown + Vel::cy[i] * LW + Vel::cx[i]];
+      d_gradient(P, nb, grad_phi);
+      const int pc = wrapp(q - 1);
+      double fn[Q], gn[Q];
+      if (MODE == 2) {
+        const long long nvol = (long long)(G.nzs - 2 * G.H) * G.plane;
+        const long long no = (long long)(pc - G.H) * G.plane + (long long)y * G.nx + x;
+#pragma unroll
+        for (int a = 0; a < Q; ++a) { fn[a] = injf[a * nvol + no]; gn[a] = injg[a * nvol + no]; }
+      } else if (MODE == 1) {
+        d_noise(P, r, ph, global_site(G, x, y, pc), noise_index, fn, gn);
+      } else {
+#pragma unroll
+        for (int a = 0; a < Q; ++a) { fn[a] = 0.; gn[a] = 0.; }
+      }
+      SiteHydro Hy;
+      d_hydrovars(P, pf, pg, r, ph, grad_rho, grad_phi, fn, gn, Hy);
+      d_collide<MODE != 0>(P, pf, pg, r, ph, Hy, fn, gn);
+      const long long o = (long long)pc * G.plane + yo[1] + x;
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        D[(long long)i * G.vol + o] = pf[i];
+        D[(long long)(i + Q) * G.vol + o] = pg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { pf[i] = cf[i]; pg[i] = cg[i]; }
+  }
+}
+
+#ifndef BFLBM_FUSED_TX
+#define BFLBM_FUSED_TX 32
 #endif
+#ifndef BFLBM_FUSED_TY
+#define BFLBM_FUSED_TY 8
+#endif
+
+// returns non-zero on launch failure
+static inline int fused_launch(const double* S, double* D, const double* injf, const double* injg,
+                               const Geo& G, const DevParams& P, int pa, int pb,
+                               uint32_t noise_index, int mode, hipStream_t stream) {
+  constexpr int TX = BFLBM_FUSED_TX, TY = BFLBM_FUSED_TY;
+  FusedGrid F;
+  F.ntx = (G.nx + TX - 1) / TX;
+  F.nty = (G.ny + TY - 1) / TY;
+  F.ncols = F.ntx * F.nty;
+  F.pa = pa; F.pb = pb;
+  const int np = pb - pa;
+  // enough chunks to fill the chip a few times over (2 workgroups resident per CU), chunks of
+  // >= 16 planes; BFLBM_FUSED_WG overrides the target workgroup count (tuning only)
+  static const int want = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 1024; }();
+  int nchunks = (want + F.ncols - 1) / F.ncols;
+  const int maxchunks = (np + 15) / 16;
+  if (nchunks > maxchunks) nchunks = maxchunks;
+  if (nchunks < 1) nchunks = 1;
+  F.lz = (np + nchunks - 1) / nchunks;
+  F.nchunks = (np + F.lz - 1) / F.lz;
+  F.total = F.ncols * F.nchunks;
+  F.per_xcd = (F.total + 7) / 8;
+  dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
+  if (mode == 2)      hipLaunchKernelGGL((k_fused<TX, TY, 2>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
+  else if (mode == 1) hipLaunchKernelGGL((k_fused<TX, TY, 1>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
+  else                hipLaunchKernelGGL((k_fused<TX, TY, 0>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
+  return hipGetLastError() != hipSuccess;
+}
+
+#endif  // BFLBM_FUSED_H_

@@ -105,8 +105,11 @@ __global__ void __launch_bounds__(256) k_density(const double* __restrict__ S, d
 }
 
 // ---- pass B: pull, project (hydrovars), draw noise, collide, store post-collision state
+#ifndef BFLBM_COLLIDE_WAVES
+#define BFLBM_COLLIDE_WAVES 2
+#endif
 template <bool NOISE, bool INJECT>
-__global__ void __launch_bounds__(256) k_collide(const double* __restrict__ S, double* __restrict__ D,
+__global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const double* __restrict__ S, double* __restrict__ D,
                                                  const double* __restrict__ rho, const double* __restrict__ phi,
                                                  const double* __restrict__ injf, const double* __restrict__ injg,
                                                  Geo G, DevParams P, int p0, uint32_t noise_index) {

@@ -1,0 +1,276 @@
+"""z-slab decomposition of the lattice over the GPUs of one node.
+
+The reference distributes boxes with AMReX (BoxArray::maxSize + DistributionMapping,
+main_run_job.cpp:140-143) and fills 113 components x 2 ghost layers on all six faces every
+step (LBM_binary.H:130-131, :312, :353, :553-555).  Here each GPU owns a contiguous z-slab;
+x and y wrap inside the slab, and one exchange per step moves exactly the populations that
+cross a z face: 38 component-planes per face (see csrc/bflbm.hip halo_table).  The exchange
+of step t's results is posted as soon as the slab's two outermost plane pairs are done and
+overlaps the interior planes of the same step:
+
+    step_boundary -> pack -> isend/irecv (RCCL stream) || step_interior -> wait -> unpack -> finish
+
+torch.distributed is plumbing only (process group, P2P); all lattice work is in the HIP library.
+`engine_factory` lets the CPU test-suite drive the same protocol with a stand-in engine.
+"""
+import numpy as np
+
+from . import _lib
+from .lattice import BinaryLBM
+
+
+def slab_bounds(nz, nranks, rank):
+    """Balanced contiguous split of nz planes."""
+    return (nz * rank) // nranks, (nz * (rank + 1)) // nranks
+
+
+class _Protocol:
+    """The per-step and upload protocols, independent of how buffers travel."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    # subclasses implement _exchange(kind, pack=True)
+    def LBM_timestep(self, nsteps=1):
+        e = self.engine
+        for _ in range(int(nsteps)):
+            e.step_boundary()
+            self._post(_lib.HALO_NEXT)
+            e.step_interior()
+            self._complete(_lib.HALO_NEXT)
+            e.step_finish()
+
+    def exchange(self, kind):
+        self._post(kind)
+        self._complete(kind)
+
+
+class SlabLattice(_Protocol):
+    """One rank's slab plus the ring exchange with its +-z neighbours via torch.distributed."""
+
+    def __init__(self, nx, ny, nz, params=None, group=None, device=None, schedule=None,
+                 engine_factory=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.n = (nx, ny, nz)
+        z0, z1 = slab_bounds(nz, self.world, self.rank)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        if engine_factory is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            engine = BinaryLBM(nx, ny, nz, params=params, z0=z0, z1=z1, rank=self.rank, nranks=self.world,
+                               device=self.device.index or 0, schedule=schedule, stream=stream)
+        else:
+            engine = engine_factory(nx, ny, nz, z0, z1, self.rank, self.world)
+        super().__init__(engine)
+        self.z0, self.z1 = z0, z1
+        self.lower = (self.rank - 1) % self.world
+        self.upper = (self.rank + 1) % self.world
+        self._bufs = None
+        self._work = None
+        if self.world > 1:
+            n = engine.halo_bytes(_lib.HALO_STATE) // 8
+            mk = lambda: torch.empty(n, dtype=torch.float64, device=self.device)
+            # send_lo goes to the lower neighbour (its high halo); recv_hi comes from the upper one
+            self._bufs = dict(send_lo=mk(), send_hi=mk(), recv_lo=mk(), recv_hi=mk())
+
+    def _ranks(self, r):
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
+    def _post(self, kind):
+        if self.world == 1:
+            return
+        e, b, dist = self.engine, self._bufs, self.dist
+        e.halo_pack(kind, 0, b["send_lo"].data_ptr())
+        e.halo_pack(kind, 1, b["send_hi"].data_ptr())
+        lo, up = self._ranks(self.lower), self._ranks(self.upper)
+        # posting order matters when lower == upper (world == 2): the peer's first recv (recv_hi,
+        # from ITS upper = me) must meet my first send (send_lo).
+        ops = [dist.P2POp(dist.isend, b["send_lo"], lo, self.group, tag=0),
+               dist.P2POp(dist.isend, b["send_hi"], up, self.group, tag=1),
+               dist.P2POp(dist.irecv, b["recv_hi"], up, self.group, tag=0),
+               dist.P2POp(dist.irecv, b["recv_lo"], lo, self.group, tag=1)]
+        self._work = dist.batch_isend_irecv(ops)
+
+    def _complete(self, kind):
+        if self.world == 1:
+            return
+        for w in self._work:
+            w.wait()
+        self._work = None
+        e, b = self.engine, self._bufs
+        e.halo_unpack(kind, 0, b["recv_lo"].data_ptr())
+        e.halo_unpack(kind, 1, b["recv_hi"].data_ptr())
+
+    # -- reference operator surface -------------------------------------------------------------
+    def LBM_init_mixture(self):
+        self.engine.LBM_init_mixture()          # analytic: halo planes are filled by the kernel
+
+    def LBM_init_stripe(self, frac):
+        self.engine.LBM_init_stripe(frac)
+
+    def LBM_init_droplet(self, r):
+        self.engine.LBM_init_droplet(r)
+
+    def LBM_init(self, f0, g0, fab=None):
+        """LBM_binary.H:632-661 with mf.ParallelCopy + FillBoundary replaced by upload + z exchange."""
+        self.engine.upload(f0, g0, fab)
+        if self.world > 1:
+            self.exchange(_lib.HALO_UPLOAD)
+        self.engine.commit_upload(True)
+        if self.world > 1:
+            self.exchange(_lib.HALO_STATE)
+
+    def populations(self, *a, **k):
+        return self.engine.populations(*a, **k)
+
+    def LBM_hydrovars_density(self, *a, **k):
+        return self.engine.LBM_hydrovars_density(*a, **k)
+
+    def LBM_hydrovars(self, *a, **k):
+        return self.engine.LBM_hydrovars(*a, **k)
+
+    def thermal_noise(self, *a, **k):
+        return self.engine.thermal_noise(*a, **k)
+
+    def update_com(self):
+        """update_com (LBM_hydrovs.H:26-60) with the four .sum() reductions as one all-reduce."""
+        s = self.torch.as_tensor(self.engine.com_sums(), dtype=self.torch.float64, device=self.device)
+        if self.world > 1:
+            self.dist.all_reduce(s, group=self.group)
+        s = s.cpu().numpy()
+        return s[1:] / s[0]
+
+    def mass(self):
+        r, p = self.engine.mass()
+        s = self.torch.tensor([r, p], dtype=self.torch.float64, device=self.device)
+        if self.world > 1:
+            self.dist.all_reduce(s, group=self.group)
+        return tuple(s.cpu().tolist())
+
+    def sync(self):
+        self.engine.sync()
+
+    def close(self):
+        self.engine.close()
+
+
+class LocalSlabRing:
+    """Several slabs of one lattice held by ONE process (all on one GPU): the same protocol with
+    device-to-device copies instead of RCCL.  Used to validate the slab path on a 1-GPU box and
+    to run lattices larger than one allocation."""
+
+    def __init__(self, nx, ny, nz, nslabs, params=None, device=0, schedule=None, engine_factory=None):
+        self.n = (nx, ny, nz)
+        self.nslabs = int(nslabs)
+        self.engines = []
+        for r in range(self.nslabs):
+            z0, z1 = slab_bounds(nz, self.nslabs, r)
+            if engine_factory is None:
+                e = BinaryLBM(nx, ny, nz, params=params, z0=z0, z1=z1, rank=r, nranks=self.nslabs,
+                              device=device, schedule=schedule)
+            else:
+                e = engine_factory(nx, ny, nz, z0, z1, r, self.nslabs)
+            self.engines.append(e)
+        self._alloc = None
+        self._bufs = None
+
+    def _buffers(self):
+        if self._bufs is None:
+            import torch
+            e0 = self.engines[0]
+            n = e0.halo_bytes(_lib.HALO_STATE) // 8
+            dev = "cuda" if isinstance(e0, BinaryLBM) else "cpu"
+            self._bufs = [[torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)] for _ in self.engines]
+        return self._bufs
+
+    def _sync_all(self):
+        for e in self.engines:
+            e.sync()
+
+    def exchange(self, kind):
+        if self.nslabs == 1:
+            return
+        bufs = self._buffers()
+        for r, e in enumerate(self.engines):
+            e.halo_pack(kind, 0, bufs[r][0].data_ptr())
+            e.halo_pack(kind, 1, bufs[r][1].data_ptr())
+        self._sync_all()                       # contexts use independent streams
+        for r, e in enumerate(self.engines):
+            lower, upper = (r - 1) % self.nslabs, (r + 1) % self.nslabs
+            e.halo_unpack(kind, 0, bufs[lower][1].data_ptr())   # lower neighbour's high face
+            e.halo_unpack(kind, 1, bufs[upper][0].data_ptr())   # upper neighbour's low face
+        self._sync_all()
+
+    def LBM_timestep(self, nsteps=1):
+        for _ in range(int(nsteps)):
+            for e in self.engines:
+                e.step_boundary()
+            for e in self.engines:
+                e.step_interior()
+            self.exchange(_lib.HALO_NEXT)
+            for e in self.engines:
+                e.step_finish()
+
+    def LBM_init_mixture(self):
+        for e in self.engines:
+            e.LBM_init_mixture()
+
+    def LBM_init_stripe(self, frac):
+        for e in self.engines:
+            e.LBM_init_stripe(frac)
+
+    def LBM_init_droplet(self, r):
+        for e in self.engines:
+            e.LBM_init_droplet(r)
+
+    def LBM_init(self, f0, g0):
+        """f0,g0: full-lattice arrays (19, nz, ny, nx)."""
+        for e in self.engines:
+            e.upload(np.ascontiguousarray(f0[:, e.z0:e.z1]), np.ascontiguousarray(g0[:, e.z0:e.z1]))
+        self.exchange(_lib.HALO_UPLOAD)
+        for e in self.engines:
+            e.commit_upload(True)
+        self.exchange(_lib.HALO_STATE)
+
+    def _gather(self, getter, ncomp):
+        nx, ny, nz = self.n
+        out = np.empty((ncomp, nz, ny, nx))
+        for e in self.engines:
+            out[:, e.z0:e.z1] = getter(e)
+        return out
+
+    def populations(self):
+        nx, ny, nz = self.n
+        f = np.empty((19, nz, ny, nx)); g = np.empty_like(f)
+        for e in self.engines:
+            a, b = e.populations()
+            f[:, e.z0:e.z1] = a; g[:, e.z0:e.z1] = b
+        return f, g
+
+    def LBM_hydrovars_density(self):
+        return self._gather(lambda e: e.LBM_hydrovars_density(), 9)
+
+    def LBM_hydrovars(self):
+        return self._gather(lambda e: e.LBM_hydrovars(), 22)
+
+    def thermal_noise(self):
+        nx, ny, nz = self.n
+        f = np.empty((19, nz, ny, nx)); g = np.empty_like(f)
+        for e in self.engines:
+            a, b = e.thermal_noise()
+            f[:, e.z0:e.z1] = a; g[:, e.z0:e.z1] = b
+        return f, g
+
+    def update_com(self):
+        s = sum(e.com_sums() for e in self.engines)
+        return s[1:] / s[0]
+
+    def close(self):
+        for e in self.engines:
+            e.close()

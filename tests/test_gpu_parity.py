@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SCHEDULES = ["two_pass"]
+SCHEDULES = ["two_pass", "fused"]
 
 
 def _same(a, b, what):
