@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--size", type=int, default=256, help="cubic box edge at N=1 / slab edge per GPU")
     ap.add_argument("--noise", action="store_true", help="kBT=1e-5 (configs[2]) instead of zero noise")
     ap.add_argument("--init", default="stripe", choices=["stripe", "droplet", "mixture"])
-    ap.add_argument("--schedule", default=os.environ.get("BFLBM_SCHEDULE", "two_pass"))
+    ap.add_argument("--schedule", default=os.environ.get("BFLBM_SCHEDULE", "fused"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 

@@ -78,6 +78,7 @@ SIGNATURES = {
     "bflbm_timer_start": (ctypes.c_int, [_vp]),
     "bflbm_timer_stop": (ctypes.c_int, [_vp, _P(ctypes.c_float)]),
     "bflbm_rng_site_normals": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _dp]),
+    "bflbm_debug_time_kernel": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _P(ctypes.c_float)]),
     "bflbm_device_bytes": (ctypes.c_int, [_vp, _P(ctypes.c_size_t)]),
 }
 

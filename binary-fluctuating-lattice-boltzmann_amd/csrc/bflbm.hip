@@ -93,7 +93,7 @@ struct bflbm_ctx {
   bool own_stream = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   long long steps = 0;
-  int schedule = 0;
+  int schedule = 1;              // 0 two-pass, 1 fused plane-marching (default)
   bool step_open = false;
   bool density_valid = false;   // rho/phi arrays hold the densities of the resident state
   size_t bytes = 0;
@@ -648,6 +648,28 @@ int bflbm_rng_site_normals(uint64_t seed, uint64_t site, uint32_t noise_index, d
     bflbm_rng_block((uint32_t)seed, (uint32_t)(seed >> 32), site, noise_index, blk, a, b, cc, d);
     out36[4 * blk] = a; out36[4 * blk + 1] = b; out36[4 * blk + 2] = cc; out36[4 * blk + 3] = d;
   }
+  return 0;
+}
+
+int bflbm_debug_time_kernel(bflbm_ctx* c, int which, int reps, float* ms) {
+  if (!c || !ms || reps < 1) return fail("bad argument");
+  if (c->step_open) return fail("diagnostics inside an open step");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  const size_t sbytes = (size_t)2 * Q * c->G.vol * sizeof(double);
+  for (int r = -1; r < reps; ++r) {
+    if (r == 0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (which == 0) hipLaunchKernelGGL(k_pull, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
+    else if (which == 1) hipLaunchKernelGGL(k_density, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->rho, c->phi, c->G, own_lo(c));
+    else if (which == 2) HIP_TRY(hipMemcpyAsync(c->S[1 - c->cur], c->S[c->cur], sbytes, hipMemcpyDeviceToDevice, c->stream));
+    else return fail("unknown diagnostic kernel %d", which);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float t = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
+  *ms = t / reps;
+  c->density_valid = false;
   return 0;
 }
 

@@ -48,45 +48,53 @@ __device__ __forceinline__ bool fused_map(const FusedGrid& F, int b, int& col, i
   return true;
 }
 
+#ifndef BFLBM_ABL
+#define BFLBM_ABL 0   // ablation switches for timing experiments only (results become wrong)
+#endif
+
+// Tile geometry: TX x TY threads, one site each, tiles aligned to TX (row segments start on
+// 128-byte lines when TX is a multiple of 16).  rho,phi of the one-site ring around the tile are
+// pulled and summed as 2*ring half-tasks (site x fluid) spread evenly over the waves.
 template <int TX, int TY, int MODE>   // MODE 0: no noise, 1: generated noise, 2: injected noise
 __global__ void __launch_bounds__(TX*TY, 2)
 k_fused(const double* __restrict__ S, double* __restrict__ D,
         const double* __restrict__ injf, const double* __restrict__ injg,
         Geo G, DevParams P, FusedGrid F, uint32_t noise_index) {
+  static_assert((TX * TY) % 64 == 0, "whole waves");
   constexpr int LW = TX + 2;                     // LDS row length
   constexpr int LSZ = (TX + 2) * (TY + 2);
-  __shared__ double rp[4][2][LSZ];               // ring of 4 planes x {rho,phi}
+  constexpr int NW = TX * TY / 64;
+  static_assert(2 * (2 * (TX + 2) + 2 * TY) <= 64 * NW, "ring half-tasks must fit one per lane");
+  __shared__ double rp[4][2][LSZ];               // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
+  __shared__ double gl[Q][TX * TY];              // g populations of the previous plane
 
   int col, chunk;
-  const bool live = fused_map(F, (int)blockIdx.x, col, chunk);
-  if (!live) return;                             // whole workgroup leaves together
+  if (!fused_map(F, (int)blockIdx.x, col, chunk)) return;   // whole workgroup leaves together
   const int tix = col % F.ntx, tiy = col / F.ntx;
   const int x0 = tix * TX, y0 = tiy * TY;
   const int aw = min(TX, G.nx - x0), ah = min(TY, G.ny - y0);   // active extent of this tile
   const int tid = threadIdx.x;
   const int tx = tid % TX, ty = tid / TX;
-  const bool own = (tx < aw) && (ty < ah);
-
-  // ---- per-thread addressing, fixed for the whole march
   auto wrapx = [&](int v) { return v < 0 ? v + G.nx : (v >= G.nx ? v - G.nx : v); };
   auto wrapy = [&](int v) { return v < 0 ? v + G.ny : (v >= G.ny ? v - G.ny : v); };
-  const int x = own ? x0 + tx : x0, y = own ? y0 + ty : y0;
-  const int xo[3] = { wrapx(x - 1), x, wrapx(x + 1) };
-  const int yo[3] = { wrapy(y - 1) * G.nx, y * G.nx, wrapy(y + 1) * G.nx };
 
-  // halo ring of the active rectangle: 2*(aw+2) + 2*ah sites, two half-tasks (f, g) each,
-  // spread evenly over the waves (lanes 0..nper-1 of each wave)
+  // ---- own site: per-thread 32-bit element offsets inside a plane, fixed for the whole march
+  const bool loader = (tx < aw) && (ty < ah);
+  const bool interior = loader;
+  const int x = loader ? x0 + tx : x0, y = loader ? y0 + ty : y0;
+  const unsigned xo[3] = { (unsigned)wrapx(x - 1), (unsigned)x, (unsigned)wrapx(x + 1) };
+  const unsigned yo[3] = { (unsigned)(wrapy(y - 1) * G.nx), (unsigned)(y * G.nx), (unsigned)(wrapy(y + 1) * G.nx) };
+  // ---- ring half-task of this thread: lanes 0..nper-1 of every wave
   const int nring = 2 * (aw + 2) + 2 * ah;
   const int ntask = 2 * nring;
-  constexpr int NW = TX * TY / 64;
   const int nper = (ntask + NW - 1) / NW;
   const int lane = tid & 63, wv = tid >> 6;
-  const int task = (lane < nper) ? wv * nper + lane : -1;
-  const bool has_task = task >= 0 && task < ntask;
+  const int task = wv * nper + lane;
+  const bool has_task = (BFLBM_ABL & 1) ? false : (lane < nper && task < ntask);
   int hfl = 0, hlx = 0, hly = 0;                 // fluid, LDS coordinates of the ring site
   if (has_task) {
     hfl = task / nring;
-    int r = task - hfl * nring;
+    const int r = task - hfl * nring;
     if (r < aw + 2) { hlx = r; hly = 0; }
     else if (r < 2 * (aw + 2)) { hlx = r - (aw + 2); hly = ah + 1; }
     else if (r < 2 * (aw + 2) + ah) { hlx = 0; hly = r - 2 * (aw + 2) + 1; }
@@ -94,9 +102,8 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   }
   const int hx = wrapx(x0 + hlx - 1);            // in [-1, nx]: one wrap suffices
   const int hy = wrapy(y0 + hly - 1);
-  const int hxo[3] = { wrapx(hx - 1), hx, wrapx(hx + 1) };
-  const int hyo[3] = { wrapy(hy - 1) * G.nx, hy * G.nx, wrapy(hy + 1) * G.nx };
-  const long long hbase = (long long)hfl * Q * G.vol;
+  const unsigned hxo[3] = { (unsigned)wrapx(hx - 1), (unsigned)hx, (unsigned)wrapx(hx + 1) };
+  const unsigned hyo[3] = { (unsigned)(wrapy(hy - 1) * G.nx), (unsigned)(hy * G.nx), (unsigned)(wrapy(hy + 1) * G.nx) };
 
   const int lown = (ty + 1) * LW + (tx + 1);
   const int lhalo = hly * LW + hlx;
@@ -109,42 +116,63 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
     return q < 0 ? q + G.nzs : (q >= G.nzs ? q - G.nzs : q);
   };
 
-  double pf[Q], pg[Q];                           // pulled populations of the previous plane
+  // Held across one march position: f of the previous plane in registers, g of the previous
+  // plane in LDS (each thread only touches its own column gl[.][tid], so no barrier is needed).
+  double pf[Q];
 #pragma unroll
-  for (int i = 0; i < Q; ++i) { pf[i] = 0.; pg[i] = 0.; }
+  for (int i = 0; i < Q; ++i) pf[i] = 0.;
 
   int it = 0;
   for (int q = qa - 1; q <= qb; ++q, ++it) {
     const int slot = it & 3;
-    const long long pl[3] = { (long long)wrapp(q - 1) * G.plane, (long long)wrapp(q) * G.plane, (long long)wrapp(q + 1) * G.plane };
-    // 1. pull plane q
-    double cf[Q], cg[Q];
-    if (own) {
+    // wave-uniform plane bases: every load below is  (SGPR base) + (32-bit lane offset)
+    const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
+                                         S + (long long)wrapp(q + 1) * G.plane };
+    // 1. pull plane q: the halo row first, then the own site; everything is in flight together
+    double hv[Q];
+    if (has_task) {
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
-        const long long o = pl[1 - Vel::cz[i]] + yo[1 - Vel::cy[i]] + xo[1 - Vel::cx[i]];
-        cf[i] = S[(long long)i * G.vol + o];
-        cg[i] = S[(long long)(i + Q) * G.vol + o];
+        const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)hfl * Q * G.vol + (long long)i * G.vol;
+        hv[i] = b[hyo[1 - Vel::cy[i]] + hxo[1 - Vel::cx[i]]];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < Q; ++i) hv[i] = 0.;
+    }
+    double cf[Q], cg[Q];
+    if (loader) {
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
+        const unsigned o = yo[1 - Vel::cy[i]] + xo[1 - Vel::cx[i]];
+        cf[i] = b[o];
+        cg[i] = b[(long long)Q * G.vol + o];
       }
     } else {
 #pragma unroll
       for (int i = 0; i < Q; ++i) { cf[i] = 0.; cg[i] = 0.; }
     }
-    double hsum = 0.0;
-    if (has_task) {
-#pragma unroll
-      for (int i = 0; i < Q; ++i) {
-        const long long o = pl[1 - Vel::cz[i]] + hyo[1 - Vel::cy[i]] + hxo[1 - Vel::cx[i]];
-        hsum += S[hbase + (long long)i * G.vol + o];
-      }
-    }
     // 2. densities of plane q into the ring slot
-    const double rq = d_density(cf), phq = d_density(cg);
-    if (own) { rp[slot][0][lown] = rq; rp[slot][1][lown] = phq; }
-    if (has_task) rp[slot][hfl][lhalo] = hsum;
+    if (has_task) rp[slot][hfl][lhalo] = d_density(hv);
+    if (loader) { rp[slot][0][lown] = d_density(cf); rp[slot][1][lown] = d_density(cg); }
     __syncthreads();
-    // 3. collide plane q-1 (registers pf,pg; slots it-2, it-1, it)
-    if (q - 1 >= qa && q - 1 < qb && own) {
+    // 3. collide plane q-1: f from registers, g streamed out of LDS while plane q's g takes its place
+    const bool do_collide = (q - 1 >= qa) && (q - 1 < qb) && interior;
+    double mg[Q], jg[3];
+    if (do_collide) {
+      double pg[Q];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) pg[i] = gl[i][tid];
+      d_moments(pg, mg);
+      d_momentum(pg, jg);
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) gl[i][tid] = cg[i];
+    if (do_collide) {
+      double mf[Q], jf[3];
+      d_moments(pf, mf);
+      d_momentum(pf, jf);
       const int sl[3] = { (it - 2) & 3, (it - 1) & 3, it & 3 };
       const double r = rp[sl[1]][0][lown], ph = rp[sl[1]][1][lown];
       double nb[Q], grad_rho[3], grad_phi[3];
@@ -158,32 +186,50 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
       double fn[Q], gn[Q];
       if (MODE == 2) {
         const long long nvol = (long long)(G.nzs - 2 * G.H) * G.plane;
-        const long long no = (long long)(pc - G.H) * G.plane + (long long)y * G.nx + x;
+        const double* __restrict__ nb_f = injf + (long long)(pc - G.H) * G.plane;
+        const double* __restrict__ nb_g = injg + (long long)(pc - G.H) * G.plane;
+        const unsigned no = yo[1] + xo[1];
 #pragma unroll
-        for (int a = 0; a < Q; ++a) { fn[a] = injf[a * nvol + no]; gn[a] = injg[a * nvol + no]; }
+        for (int a = 0; a < Q; ++a) { fn[a] = nb_f[a * nvol + no]; gn[a] = nb_g[a * nvol + no]; }
       } else if (MODE == 1) {
         d_noise(P, r, ph, global_site(G, x, y, pc), noise_index, fn, gn);
       } else {
 #pragma unroll
         for (int a = 0; a < Q; ++a) { fn[a] = 0.; gn[a] = 0.; }
       }
-      SiteHydro Hy;
-      d_hydrovars(P, pf, pg, r, ph, grad_rho, grad_phi, fn, gn, Hy);
-      d_collide<MODE != 0>(P, pf, pg, r, ph, Hy, fn, gn);
-      const long long o = (long long)pc * G.plane + yo[1] + x;
+      double* __restrict__ Dp = D + (long long)pc * G.plane;
+      const unsigned o = yo[1] + xo[1];
+      if (BFLBM_ABL & 2) {
 #pragma unroll
-      for (int i = 0; i < Q; ++i) {
-        D[(long long)i * G.vol + o] = pf[i];
-        D[(long long)(i + Q) * G.vol + o] = pg[i];
+        for (int i = 0; i < Q; ++i) { Dp[(long long)i * G.vol + o] = mf[i] + grad_rho[0]; Dp[(long long)(i + Q) * G.vol + o] = mg[i] + grad_phi[1]; }
+      } else {
+        SiteHydro Hy;
+        d_hydrovars_j(P, jf, jg, r, ph, grad_rho, grad_phi, fn, gn, Hy);
+        double v_b[3];
+        d_barycentric(r, ph, Hy, v_b);
+        {
+          d_relax<MODE != 0>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn);
+          double out[Q];
+          d_populations(mf, out);
+#pragma unroll
+          for (int i = 0; i < Q; ++i) Dp[(long long)i * G.vol + o] = out[i];
+        }
+        {
+          d_relax<MODE != 0>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn);
+          double out[Q];
+          d_populations(mg, out);
+#pragma unroll
+          for (int i = 0; i < Q; ++i) Dp[(long long)(i + Q) * G.vol + o] = out[i];
+        }
       }
     }
 #pragma unroll
-    for (int i = 0; i < Q; ++i) { pf[i] = cf[i]; pg[i] = cg[i]; }
+    for (int i = 0; i < Q; ++i) pf[i] = cf[i];
   }
 }
 
 #ifndef BFLBM_FUSED_TX
-#define BFLBM_FUSED_TX 32
+#define BFLBM_FUSED_TX 64
 #endif
 #ifndef BFLBM_FUSED_TY
 #define BFLBM_FUSED_TY 8
@@ -202,7 +248,7 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   const int np = pb - pa;
   // enough chunks to fill the chip a few times over (2 workgroups resident per CU), chunks of
   // >= 16 planes; BFLBM_FUSED_WG overrides the target workgroup count (tuning only)
-  static const int want = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 1024; }();
+  static const int want = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 512; }();
   int nchunks = (want + F.ncols - 1) / F.ncols;
   const int maxchunks = (np + 15) / 16;
   if (nchunks > maxchunks) nchunks = maxchunks;

@@ -39,6 +39,30 @@ struct DevParams {
   int noise_on;                 // kBT != 0
 };
 
+// RN(x/3) and RN(x/9) with one multiply and two FMAs instead of the ~10-instruction IEEE
+// division sequence.  Exactness (for normal x, no under/overflow): write x = X*2^e with X a
+// 53-bit integer.  X/3 = k + r/3, r in {0,1,2}; the floats near X/3 are spaced 1/4 or 1/2 and the
+// rounding midpoints are odd multiples of 1/8 or 1/4, so X/3 is either a float or at least 1/6 ulp
+// away from every midpoint.  For 9: X/9 = k + r/9, spacing 1/16 or 1/8, and |r/9 - (2j+1)/32| =
+// |32 r - 9 (2j+1)|/288 >= 1/288 (odd numerator), i.e. at least 1/18 ulp from every midpoint.
+// q0 = RN(x*y), y = RN(1/d), is within 1.5 ulp of x/d; rem = x - d*q0 is an integer multiple
+// (|.| <= 13) of ulp(q0), hence exact in the FMA; q0 + rem*y = x/d + (x/d - q0)*eps with
+// |eps| <= 2^-53, i.e. within 2^-52 ulp of x/d, far inside the 1/18 ulp margin, so the final
+// FMA rounding returns RN(x/d).  Division by 36, 12, 24, 48, 72 (LBM_d3q19.H:175-193) is one of
+// these followed by an exact power-of-two scaling.  tools/div_probe.hip checks 2^32 samples.
+__device__ __forceinline__ double d_div3(double x) {
+  const double y = 0x1.5555555555555p-2;
+  const double q = x * y;
+  const double r = __builtin_fma(-3.0, q, x);
+  return __builtin_fma(r, y, q);
+}
+__device__ __forceinline__ double d_div9(double x) {
+  const double y = 0x1.c71c71c71c71cp-4;
+  const double q = x * y;
+  const double r = __builtin_fma(-9.0, q, x);
+  return __builtin_fma(r, y, q);
+}
+
 // populations -> moments (LBM_d3q19.H:100-156)
 __device__ __forceinline__ void d_moments(const double (&fs)[Q], double (&m)[Q]) {
   double f;
@@ -90,25 +114,26 @@ __device__ __forceinline__ void d_moments(const double (&fs)[Q], double (&m)[Q])
 // moments -> populations (LBM_d3q19.H:167-247)
 __device__ __forceinline__ void d_populations(const double (&mom)[Q], double (&f)[Q]) {
   double m[Q];
-  m[0]  = mom[0]  / 36.;
-  m[1]  = mom[1]  / 12.;
-  m[2]  = mom[2]  / 12.;
-  m[3]  = mom[3]  / 12.;
-  m[4]  = mom[4]  / 24.;
-  m[5]  = mom[5]  / 48.;
-  m[6]  = mom[6]  / 16.;
-  m[7]  = mom[7]  / 4.;
-  m[8]  = mom[8]  / 4.;
-  m[9]  = mom[9]  / 4.;
-  m[10] = mom[10] / 24.;
-  m[11] = mom[11] / 24.;
-  m[12] = mom[12] / 24.;
-  m[13] = mom[13] / 8.;
-  m[14] = mom[14] / 8.;
-  m[15] = mom[15] / 8.;
-  m[16] = mom[16] / 72.;
-  m[17] = mom[17] / 48.;
-  m[18] = mom[18] / 16.;
+  // mom/{36,12,12,12,24,48,16,4,4,4,24,24,24,8,8,8,72,48,16}, bit-identical to the divisions
+  m[0]  = d_div9(mom[0])  * 0.25;
+  m[1]  = d_div3(mom[1])  * 0.25;
+  m[2]  = d_div3(mom[2])  * 0.25;
+  m[3]  = d_div3(mom[3])  * 0.25;
+  m[4]  = d_div3(mom[4])  * 0.125;
+  m[5]  = d_div3(mom[5])  * 0.0625;
+  m[6]  = mom[6]  * 0.0625;
+  m[7]  = mom[7]  * 0.25;
+  m[8]  = mom[8]  * 0.25;
+  m[9]  = mom[9]  * 0.25;
+  m[10] = d_div3(mom[10]) * 0.125;
+  m[11] = d_div3(mom[11]) * 0.125;
+  m[12] = d_div3(mom[12]) * 0.125;
+  m[13] = mom[13] * 0.125;
+  m[14] = mom[14] * 0.125;
+  m[15] = mom[15] * 0.125;
+  m[16] = d_div9(mom[16]) * 0.125;
+  m[17] = d_div3(mom[17]) * 0.0625;
+  m[18] = mom[18] * 0.0625;
 
   const double mc0 = 12.*(m[0] - m[4] + m[16]);
   const double mc1 =  2.*(m[0] - 2.*m[16]);
@@ -240,13 +265,10 @@ struct SiteHydro {
   double nfvel[3], ngvel[3];
 };
 
-__device__ __forceinline__ void d_hydrovars(const DevParams& P, const double (&fs)[Q], const double (&gs)[Q],
-                                            double rho, double phi,
-                                            const double (&grad_rho)[3], const double (&grad_phi)[3],
-                                            const double (&nf)[Q], const double (&ng)[Q], SiteHydro& H) {
-  double jf[3], jg[3];
-  d_momentum(fs, jf);
-  d_momentum(gs, jg);
+__device__ __forceinline__ void d_hydrovars_j(const DevParams& P, const double (&jf)[3], const double (&jg)[3],
+                                              double rho, double phi,
+                                              const double (&grad_rho)[3], const double (&grad_phi)[3],
+                                              const double (&nf)[Q], const double (&ng)[Q], SiteHydro& H) {
   const bool okr = fabs(rho) > (double)FLT_EPSILON;
   const bool okp = fabs(phi) > (double)FLT_EPSILON;
   const double wphi = P.kf*phi/(rho+phi);
@@ -262,6 +284,16 @@ __device__ __forceinline__ void d_hydrovars(const DevParams& P, const double (&f
     H.uf[k] = H.ufbar[k] + 0.5*H.af[k] - wphi*(H.ufbar[k]-H.ugbar[k] + 0.5*(H.af[k]-H.ag[k])) + 0.5*H.nfvel[k];
     H.ug[k] = H.ugbar[k] + 0.5*H.ag[k] - wrho*(H.ugbar[k]-H.ufbar[k] + 0.5*(H.ag[k]-H.af[k])) + 0.5*H.ngvel[k];
   }
+}
+
+__device__ __forceinline__ void d_hydrovars(const DevParams& P, const double (&fs)[Q], const double (&gs)[Q],
+                                            double rho, double phi,
+                                            const double (&grad_rho)[3], const double (&grad_phi)[3],
+                                            const double (&nf)[Q], const double (&ng)[Q], SiteHydro& H) {
+  double jf[3], jg[3];
+  d_momentum(fs, jf);
+  d_momentum(gs, jg);
+  d_hydrovars_j(P, jf, jg, rho, phi, grad_rho, grad_phi, nf, ng, H);
 }
 
 // equilibrium_moments (LBM_binary.H:356-402): only modes 0..9 are non-zero.
@@ -305,6 +337,35 @@ __device__ __forceinline__ void d_force_moments(const DevParams& P, double rho, 
   mPhi[9] = P.modifactor*P.cs4*(A02 + A20);
 }
 
+// The relaxation loop of collide (LBM_binary.H:504-511) for one fluid, in moment space:
+// m += (mEq - m)/tau_bar + mPhi + noise, with the fluid's density rho_k, the barycentric
+// velocity v_b (equilibrium), its own real velocity u and acceleration a (force moments).
+template <bool NOISE>
+__device__ __forceinline__ void d_relax(const DevParams& P, double (&m)[Q], double rho_k, const double (&v_b)[3],
+                                        const double (&u)[3], const double (&a)[3], double inv_tau_bar,
+                                        const double (&noise)[Q]) {
+  double mEq[10], mPhi[10];
+  d_equilibrium(P, rho_k, v_b, mEq);
+  d_force_moments(P, rho_k, u, a, mPhi);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    double R = inv_tau_bar*(mEq[k] - m[k]) + mPhi[k];
+    if (NOISE) R = R + noise[k];
+    m[k] = m[k] + R;
+  }
+#pragma unroll
+  for (int k = 10; k < Q; ++k) {
+    double R = inv_tau_bar*(0. - m[k]) + 0.;
+    if (NOISE) R = R + noise[k];
+    m[k] = m[k] + R;
+  }
+}
+
+__device__ __forceinline__ void d_barycentric(double rho, double phi, const SiteHydro& H, double (&v_b)[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v_b[k] = (rho*H.uf[k] + phi*H.ug[k])/(rho + phi);   // LBM_binary.H:471
+}
+
 // collide (LBM_binary.H:451-516): fs,gs are replaced by the post-collision populations.
 // NOISE=false drops the noise terms (they are exactly +-0 when kBT == 0).
 template <bool NOISE>
@@ -312,44 +373,17 @@ __device__ __forceinline__ void d_collide(const DevParams& P, double (&fs)[Q], d
                                           double rho, double phi, const SiteHydro& H,
                                           const double (&fn)[Q], const double (&gn)[Q]) {
   double v_b[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) v_b[k] = (rho*H.uf[k] + phi*H.ug[k])/(rho + phi);
+  d_barycentric(rho, phi, H, v_b);
   {
-    double m[Q], mEq[10], mPhi[10];
+    double m[Q];
     d_moments(fs, m);
-    d_equilibrium(P, rho, v_b, mEq);
-    d_force_moments(P, rho, H.uf, H.af, mPhi);
-#pragma unroll
-    for (int a = 0; a < 10; ++a) {
-      double R = P.inv_tau_f_bar*(mEq[a] - m[a]) + mPhi[a];
-      if (NOISE) R = R + fn[a];
-      m[a] = m[a] + R;
-    }
-#pragma unroll
-    for (int a = 10; a < Q; ++a) {
-      double R = P.inv_tau_f_bar*(0. - m[a]) + 0.;
-      if (NOISE) R = R + fn[a];
-      m[a] = m[a] + R;
-    }
+    d_relax<NOISE>(P, m, rho, v_b, H.uf, H.af, P.inv_tau_f_bar, fn);
     d_populations(m, fs);
   }
   {
-    double m[Q], mEq[10], mPhi[10];
+    double m[Q];
     d_moments(gs, m);
-    d_equilibrium(P, phi, v_b, mEq);
-    d_force_moments(P, phi, H.ug, H.ag, mPhi);
-#pragma unroll
-    for (int a = 0; a < 10; ++a) {
-      double R = P.inv_tau_g_bar*(mEq[a] - m[a]) + mPhi[a];
-      if (NOISE) R = R + gn[a];
-      m[a] = m[a] + R;
-    }
-#pragma unroll
-    for (int a = 10; a < Q; ++a) {
-      double R = P.inv_tau_g_bar*(0. - m[a]) + 0.;
-      if (NOISE) R = R + gn[a];
-      m[a] = m[a] + R;
-    }
+    d_relax<NOISE>(P, m, phi, v_b, H.ug, H.ag, P.inv_tau_g_bar, gn);
     d_populations(m, gs);
   }
 }

@@ -253,6 +253,12 @@ class BinaryLBM:
         check(self.lib.bflbm_timer_stop(self._h, ctypes.byref(ms)))
         return ms.value
 
+    def debug_time_kernel(self, which, reps=10):
+        """ms per launch of a calibration kernel (0 pull-copy, 1 density pass, 2 D2D memcpy)."""
+        ms = ctypes.c_float()
+        check(self.lib.bflbm_debug_time_kernel(self._h, int(which), int(reps), ctypes.byref(ms)))
+        return ms.value
+
     def device_bytes(self):
         n = ctypes.c_size_t()
         check(self.lib.bflbm_device_bytes(self._h, ctypes.byref(n)))

@@ -171,6 +171,12 @@ int bflbm_timer_stop(bflbm_ctx* c, float* ms);
  * kernels use the same code); 36 values, 33 consumed per site and noise index. */
 int bflbm_rng_site_normals(uint64_t seed, uint64_t site, uint32_t noise_index, double* out36);
 
+/* Diagnostics: time `reps` launches of a streaming kernel over the slab (hipEvents), for
+ * roofline calibration.  which: 0 = pull-copy (38 shifted reads + 38 writes per site),
+ * 1 = density pass (38 reads + 2 writes), 2 = hipMemcpyAsync device-to-device of one buffer.
+ * The resident state is not modified (scratch buffer is overwritten). */
+int bflbm_debug_time_kernel(bflbm_ctx* c, int which, int reps, float* ms_per_launch);
+
 /* Device bytes held by the context. */
 int bflbm_device_bytes(const bflbm_ctx* c, size_t* bytes);
 
