@@ -1,7 +1,7 @@
 """ctypes binding of the C-ABI in include/bflbm.h (libbflbm.so, built by csrc/Makefile).
 
 There is deliberately no CPU fallback: if the HIP library is missing or fails to load,
-importing the product path raises.  The CPU oracle under oracle/ is test infrastructure
+importing the product path raises.  The CPU checker used by the tests is test infrastructure
 and is never imported from here.
 """
 import ctypes

@@ -319,10 +319,11 @@ void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
 /* ------------------------------------------------------------------ */
 /* thermal_noise, LBM_binary.H:73-132 (non-USE_REF_STATE branch, :109-111).
  * Draw order per site: modes 1..3, then (f,g) interleaved for modes 4..18.
- * z_off = global z of local plane 0 and gnz = global nz (for slab tests). */
-void orc_thermal_noise(const orc_params* p, int nx, int ny, int nz,
-                       const double* hbar, uint32_t noise_index,
-                       double* fn, double* gn) {
+ * gz0 = global z of local plane 0 and gnz = global nz (slab tests; the site id that keys the
+ * random stream is the GLOBAL lattice index). */
+void orc_thermal_noise_slab(const orc_params* p, int nx, int ny, int nz, int gz0, int gnz,
+                            const double* hbar, uint32_t noise_index,
+                            double* fn, double* gn) {
   const double tau_f_bar = 1./(p->tau_f+0.5);
   const double tau_g_bar = tau_f_bar;                /* :80 (sic) */
   const double tau_f_bar2 = tau_f_bar*tau_f_bar;
@@ -333,7 +334,8 @@ void orc_thermal_noise(const orc_params* p, int nx, int ny, int nz,
     double phi = hbar[IDX(nx,ny,nz,1,x,y,z)];
     double rhot = rho + phi;
     double nrm[36];
-    uint64_t site = (uint64_t)x + (uint64_t)nx*((uint64_t)y + (uint64_t)ny*(uint64_t)z);
+    int gz = (z + gz0) % gnz; if (gz < 0) gz += gnz;
+    uint64_t site = (uint64_t)x + (uint64_t)nx*((uint64_t)y + (uint64_t)ny*(uint64_t)gz);
     orc_site_normals(p->seed, site, noise_index, nrm);
     int d = 0;
     fn[IDX(nx,ny,nz,0,x,y,z)] = 0.;
@@ -348,6 +350,11 @@ void orc_thermal_noise(const orc_params* p, int nx, int ny, int nz,
       gn[IDX(nx,ny,nz,a,x,y,z)] = sqrt(2.*(tau_g_bar - 0.5*tau_g_bar2)*kBT/cs2*B[a]*fabs(phi))*nrm[d++];
     }
   }
+}
+
+void orc_thermal_noise(const orc_params* p, int nx, int ny, int nz,
+                       const double* hbar, uint32_t noise_index, double* fn, double* gn) {
+  orc_thermal_noise_slab(p, nx, ny, nz, 0, nz, hbar, noise_index, fn, gn);
 }
 
 /* gradient, LBM_binary.H:134-150 (use_SC_pseudo == false, :23) */
