@@ -100,6 +100,15 @@ def load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C "
             f"{os.path.dirname(LIB_PATH)}). There is no CPU fallback.")
+    # torch bundles its own ROCm runtime (libamdhip64.so.7, same soname as /opt/rocm's).  Whichever
+    # copy is loaded first serves the process; if ours came first, torch would load a second copy
+    # that cannot see the GPU ("No HIP GPUs are available").  Importing torch first makes both
+    # sides share torch's runtime (measured on MI355X: tools/order_probe.py).
+    if os.environ.get("BFLBM_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing

@@ -1,0 +1,95 @@
+"""GPU: BASELINE.json's full sizes, through size-independent properties (the oracle cannot run
+256^3/512^3 in seconds): schedule equivalence, translation invariance of the stripe, mass
+conservation, golden fixtures, upload/download round trip."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_fixtures(pkg):
+    """tests/golden/oracle_trajectories.npz (written by tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_trajectories.npz"))
+    for key in [k[:-2] for k in g.files if k.endswith("_f")]:
+        name, n, steps = key.split("-")
+        n = tuple(int(v) for v in n.split("x"))
+        for schedule in ("two_pass", "fused"):
+            lbm = pkg.BinaryLBM(*n, schedule=schedule)
+            {"stripe": lambda: lbm.LBM_init_stripe(0.5), "droplet": lambda: lbm.LBM_init_droplet(0.3),
+             "mixture": lbm.LBM_init_mixture}[name]()
+            lbm.LBM_timestep(int(steps))
+            f, gg = lbm.populations()
+            assert np.array_equal(f, g[key + "_f"]) and np.array_equal(gg, g[key + "_g"]), (key, schedule)
+            assert np.array_equal(lbm.LBM_hydrovars(), g[key + "_h"]), (key, schedule)
+            lbm.close()
+
+
+def test_256_cubed_schedules_agree_and_conserve_mass(pkg):
+    """configs[1]: 256^3, zero noise.  The fused and the two-pass schedule are different kernels
+    with different tilings; identical doubles after 20 steps is a checksum over all indexing."""
+    n = 256
+    res = {}
+    for schedule in ("two_pass", "fused"):
+        lbm = pkg.BinaryLBM(n, n, n, schedule=schedule)
+        lbm.LBM_init_droplet(0.2)
+        m0 = lbm.mass()
+        lbm.LBM_timestep(20)
+        m1 = lbm.mass()
+        assert abs(m1[0] - m0[0]) <= 1e-12 * m0[0] and abs(m1[1] - m0[1]) <= 1e-12 * m0[1]
+        res[schedule] = lbm.LBM_hydrovars_density()
+        com = lbm.update_com()
+        np.testing.assert_allclose(com, [n / 2, n / 2, n / 2], atol=1e-6)    # droplet centred at box/2
+        lbm.close()
+    assert np.array_equal(res["two_pass"], res["fused"])
+
+
+def test_256_cubed_stripe_is_translation_invariant(pkg):
+    """Flat interface: the state depends on z only, so after any number of steps every (x,y) column
+    must hold bitwise the same doubles -- any mis-indexed tile, wrap or halo breaks this."""
+    n = 256
+    lbm = pkg.BinaryLBM(n, n, n)
+    lbm.LBM_init_stripe(0.5)
+    lbm.LBM_timestep(25)
+    hb = lbm.LBM_hydrovars_density()
+    for comp in range(9):
+        col = hb[comp, :, 0, 0]
+        assert np.array_equal(hb[comp], np.broadcast_to(col[:, None, None], hb[comp].shape)), comp
+    # no flow in x, y beyond the rounding residue of ((a-b)+b)-a in the gradient stencil
+    assert np.abs(hb[2]).max() < 1e-14 and np.abs(hb[3]).max() < 1e-14
+    # z-mirror symmetry of the stripe about the box centre (profile is even in pos = z - nz/2)
+    rho = hb[0, :, 0, 0]
+    np.testing.assert_allclose(rho[1:], rho[1:][::-1], rtol=0, atol=1e-13)
+    lbm.close()
+
+
+def test_512_cubed_step_runs_and_conserves_mass(pkg):
+    """North-star size on one GPU (82 GB resident): droplet init, a few steps, mass and symmetry."""
+    n = 512
+    lbm = pkg.BinaryLBM(n, n, n)
+    assert lbm.device_bytes() > 80e9
+    lbm.LBM_init_stripe(0.5)
+    m0 = lbm.mass()
+    lbm.LBM_timestep(6)
+    m1 = lbm.mass()
+    assert abs(m1[0] - m0[0]) <= 1e-12 * m0[0] and abs(m1[1] - m0[1]) <= 1e-12 * m0[1]
+    assert abs(m0[0] + m0[1] - n ** 3) <= 1e-9 * n ** 3
+    lbm.close()
+
+
+def test_upload_download_roundtrip_128(pkg):
+    n = 128
+    rng = np.random.default_rng(4)
+    f0 = rng.random((19, n, n, n))
+    g0 = rng.random((19, n, n, n))
+    lbm = pkg.BinaryLBM(n, n, n)
+    lbm.LBM_init(f0, g0)
+    f, g = lbm.populations()
+    assert np.array_equal(f, f0) and np.array_equal(g, g0)
+    hb = lbm.LBM_hydrovars_density()
+    acc = np.zeros((n, n, n))
+    for i in range(19):
+        acc += f0[i]
+    assert np.array_equal(hb[0], acc)              # sequential sum in index order (LBM_binary.H:322-328)
+    lbm.close()
