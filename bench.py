@@ -34,11 +34,14 @@ def cpu_baseline():
 
 
 def load_traffic(workload, schedule):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/make_profiles.py); null when this workload has not been profiled."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
             t = json.load(fh)
-        return t.get(f"{workload}|{schedule}")
+        e = t.get(f"{workload}|{schedule}")
+        return None if e is None else e["hbm_bytes_per_launch"]
     except Exception:
         return None
 
