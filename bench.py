@@ -71,7 +71,8 @@ def main():
     par = dict(kBT=1e-5, alpha0=0.0) if a.noise else {}
     params = pkg.default_params(**par)
 
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -99,7 +100,7 @@ def main():
     dev_ms = eng.timer_stop()              # hipEvents on the stream the kernels run on
     barrier()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
@@ -132,7 +133,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         lat.close()

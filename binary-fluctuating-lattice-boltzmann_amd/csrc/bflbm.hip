@@ -322,12 +322,14 @@ int bflbm_get_params(const bflbm_ctx* c, bflbm_params* p) {
   return 0;
 }
 
-int bflbm_set_stream(bflbm_ctx* c, void* s) {
+int bflbm_set_stream(bflbm_ctx* c, void* s, int external) {
   if (!c) return fail("null context");
+  HIP_TRY(hipSetDevice(c->dom.device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (s) {
+  if (external) {
     if (c->own_stream) hipStreamDestroy(c->stream);
-    c->stream = (hipStream_t)s; c->own_stream = false;
+    c->stream = (hipStream_t)s;            // may be the null (legacy default) stream
+    c->own_stream = false;
   } else if (!c->own_stream) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;

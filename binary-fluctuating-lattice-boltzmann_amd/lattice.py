@@ -73,8 +73,8 @@ class BinaryLBM:
         h = ctypes.c_void_p()
         check(self.lib.bflbm_create(ctypes.byref(self.params), ctypes.byref(dom), ctypes.byref(h)))
         self._h = h
-        if stream is not None:
-            check(self.lib.bflbm_set_stream(self._h, ctypes.c_void_p(stream)))
+        if stream is not None:      # an external hipStream_t handle; 0 is the legacy default stream
+            check(self.lib.bflbm_set_stream(self._h, ctypes.c_void_p(stream), 1))
         if schedule is not None:
             self.set_schedule(schedule)
 

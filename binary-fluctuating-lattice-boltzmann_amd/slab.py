@@ -73,6 +73,9 @@ class SlabLattice(_Protocol):
         self.upper = (self.rank + 1) % self.world
         self._bufs = None
         self._work = None
+        # RCCL orders its work after the current stream by itself; host-driven backends (gloo) read
+        # the send buffers from the host side, so the pack kernels must have completed first.
+        self._host_sync = dist.get_backend(group) != "nccl"
         if self.world > 1:
             n = engine.halo_bytes(_lib.HALO_STATE) // 8
             mk = lambda: torch.empty(n, dtype=torch.float64, device=self.device)
@@ -88,6 +91,8 @@ class SlabLattice(_Protocol):
         e, b, dist = self.engine, self._bufs, self.dist
         e.halo_pack(kind, 0, b["send_lo"].data_ptr())
         e.halo_pack(kind, 1, b["send_hi"].data_ptr())
+        if self._host_sync:
+            e.sync()
         lo, up = self._ranks(self.lower), self._ranks(self.upper)
         # posting order matters when lower == upper (world == 2): the peer's first recv (recv_hi,
         # from ITS upper = me) must meet my first send (send_lo).

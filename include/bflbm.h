@@ -86,8 +86,10 @@ int bflbm_destroy(bflbm_ctx* c);
 int bflbm_set_params(bflbm_ctx* c, const bflbm_params* p);
 int bflbm_get_params(const bflbm_ctx* c, bflbm_params* p);
 
-/* Use the caller's hipStream_t (e.g. torch's current stream) for all work. NULL = own stream. */
-int bflbm_set_stream(bflbm_ctx* c, void* hip_stream);
+/* external != 0: enqueue all work on the caller's hipStream_t (e.g. torch's current stream; the
+ * handle may be NULL = the legacy default stream, which is what torch uses by default).
+ * external == 0: go back to the context's own non-blocking stream (hip_stream ignored). */
+int bflbm_set_stream(bflbm_ctx* c, void* hip_stream, int external);
 
 /* Kernel schedule: 0 = two-pass (density pass + collide pass), 1 = fused plane-marching kernel. */
 int bflbm_set_schedule(bflbm_ctx* c, int schedule);

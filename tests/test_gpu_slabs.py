@@ -2,6 +2,8 @@
 slab contexts on one GPU (slab.LocalSlabRing: same protocol as the RCCL driver, device-to-device
 copies instead of sends), bit for bit against the single-box oracle; and the torch.distributed
 driver itself with world_size 1."""
+import os
+
 import numpy as np
 import pytest
 
@@ -102,3 +104,52 @@ def test_distributed_driver_world_size_one(pkg, ob):
         lat.close()
     finally:
         dist.destroy_process_group()
+
+
+def _gloo_gpu_worker(rank, world, port, outdir, n, steps, par):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lat = pkg.SlabLattice(*n, params=pkg.default_params(**par), device=torch.device("cuda", 0))
+    lat.LBM_init_droplet(0.3)
+    lat.LBM_timestep(steps)
+    torch.cuda.synchronize()
+    f, g = lat.populations()
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), f=f, g=g, h=lat.LBM_hydrovars(), z0=lat.z0, z1=lat.z1,
+             com=lat.update_com(), mass=np.array(lat.mass()))
+    dist.barrier()
+    lat.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_driver_ranks_sharing_one_gpu(ob, world):
+    """The real driver (slab.SlabLattice + HIP engine + torch.distributed P2P with device buffers),
+    `world` ranks on the one GPU of the test box over gloo (RCCL refuses several ranks per device)."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    n, steps, par = (10, 9, 16), 5, dict(kBT=1e-5, alpha0=2.0, seed=5)
+    with tempfile.TemporaryDirectory() as d:
+        mp.get_context("spawn")
+        mp.spawn(_gloo_gpu_worker, args=(world, port, d, n, steps, par), nprocs=world, join=True)
+        ref = ob.OracleLattice(*n, params=ob.default_params(**par))
+        ref.init_droplet(0.3)
+        for _ in range(steps):
+            ref.timestep()
+        for r in range(world):
+            o = np.load(os.path.join(d, f"r{r}.npz"))
+            z0, z1 = int(o["z0"]), int(o["z1"])
+            _same(o["f"], ref.f[:, z0:z1], f"rank {r} f")
+            _same(o["g"], ref.g[:, z0:z1], f"rank {r} g")
+            _same(o["h"], ref.h[:, z0:z1], f"rank {r} hydrovs")
+            np.testing.assert_allclose(o["com"], ref.com(), rtol=1e-12)
+            np.testing.assert_allclose(o["mass"], [ref.hbar[0].sum(), ref.hbar[1].sum()], rtol=1e-12)
