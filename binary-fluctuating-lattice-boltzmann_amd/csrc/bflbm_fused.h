@@ -204,18 +204,20 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
         for (int i = 0; i < Q; ++i) { Dp[(long long)i * G.vol + o] = mf[i] + grad_rho[0]; Dp[(long long)(i + Q) * G.vol + o] = mg[i] + grad_phi[1]; }
       } else {
         SiteHydro Hy;
-        d_hydrovars_j(P, jf, jg, r, ph, grad_rho, grad_phi, fn, gn, Hy);
+        SiteRecip R;
+        d_site_recips(P, r, ph, R);
+        d_hydrovars_j(P, jf, jg, r, ph, grad_rho, grad_phi, fn, gn, Hy, R);
         double v_b[3];
-        d_barycentric(r, ph, Hy, v_b);
+        d_barycentric(r, ph, Hy, v_b, R);
         {
-          d_relax<MODE != 0>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn);
+          d_relax<MODE != 0>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn, R.cs4);
           double out[Q];
           d_populations(mf, out);
 #pragma unroll
           for (int i = 0; i < Q; ++i) Dp[(long long)i * G.vol + o] = out[i];
         }
         {
-          d_relax<MODE != 0>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn);
+          d_relax<MODE != 0>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn, R.cs4);
           double out[Q];
           d_populations(mg, out);
 #pragma unroll

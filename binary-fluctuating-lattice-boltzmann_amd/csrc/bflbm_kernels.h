@@ -136,8 +136,10 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
     for (int a = 0; a < Q; ++a) { fn[a] = 0.; gn[a] = 0.; }
   }
   SiteHydro Hy;
-  d_hydrovars(P, fs, gs, r, ph, grad_rho, grad_phi, fn, gn, Hy);
-  d_collide<NOISE || INJECT>(P, fs, gs, r, ph, Hy, fn, gn);
+  SiteRecip R;
+  d_site_recips(P, r, ph, R);
+  d_hydrovars(P, fs, gs, r, ph, grad_rho, grad_phi, fn, gn, Hy, R);
+  d_collide<NOISE || INJECT>(P, fs, gs, r, ph, Hy, fn, gn, R);
 #pragma unroll
   for (int i = 0; i < Q; ++i) {
     D[(long long)i*G.vol + o] = fs[i];
@@ -249,14 +251,16 @@ __global__ void __launch_bounds__(256) k_observe(const double* __restrict__ S, c
   gather_field(rho, I, nb); d_gradient(P, nb, grad_rho);
   gather_field(phi, I, nb); d_gradient(P, nb, grad_phi);
   SiteHydro Hy;
-  d_hydrovars(P, fs, gs, r, ph, grad_rho, grad_phi, fn, gn, Hy);
+  SiteRecip R;
+  d_site_recips(P, r, ph, R);
+  d_hydrovars(P, fs, gs, r, ph, grad_rho, grad_phi, fn, gn, Hy, R);
   double h[BFLBM_NHYDRO_];
   h[0] = r; h[1] = ph; h[5] = r + ph;
   const double rho_tot = r + ph;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     h[2+k] = Hy.uf[k]; h[6+k] = Hy.ug[k]; h[9+k] = Hy.af[k]; h[12+k] = Hy.ag[k];
-    h[15+k] = (r*Hy.ufbar[k] + ph*Hy.ugbar[k] + 0.5*(r*Hy.af[k] + ph*Hy.ag[k]))/rho_tot;
+    h[15+k] = d_div(r*Hy.ufbar[k] + ph*Hy.ugbar[k] + 0.5*(r*Hy.af[k] + ph*Hy.ag[k]), rho_tot, R.tot);
   }
   h[18] = Hy.nfvel[0]; h[19] = Hy.ngvel[0]; h[20] = Hy.ufbar[0]; h[21] = Hy.ugbar[0];
 #pragma unroll

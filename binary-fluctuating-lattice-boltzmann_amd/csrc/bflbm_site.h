@@ -63,6 +63,32 @@ __device__ __forceinline__ double d_div9(double x) {
   return __builtin_fma(r, y, q);
 }
 
+// IEEE division a/b with the reciprocal of b shared between numerators.  hipcc expands a/b into
+//   v_div_scale x2, v_rcp_f64, 4 FMAs refining the reciprocal, q = a*y, r = fma(-b,q,a),
+//   v_div_fmas (= fma(r,y,q) plus the range scaling), v_div_fixup (specials)
+// d_recip/d_div perform exactly those operations on unscaled operands, so for finite operands
+// whose quotient and reciprocal are far from the over/underflow thresholds (always the case for
+// densities, velocities and cs4) the result is bit-identical to a/b; tools/div_probe.hip checks it.
+// The per-site denominators are only rho, phi, rho+phi and the uniform cs4: 53 divisions become
+// 4 reciprocals + 53 x (mul + 2 fma).
+__device__ __forceinline__ double d_recip(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  return y;
+}
+__device__ __forceinline__ double d_div(double a, double b, double yb) {
+  const double q = a * yb;
+  const double r = __builtin_fma(-b, q, a);
+  return __builtin_fma(r, yb, q);
+}
+struct SiteRecip { double rho, phi, tot, cs4; };   // refined reciprocals of rho, phi, rho+phi, cs4
+__device__ __forceinline__ void d_site_recips(const DevParams& P, double rho, double phi, SiteRecip& R) {
+  R.rho = d_recip(rho); R.phi = d_recip(phi); R.tot = d_recip(rho + phi); R.cs4 = d_recip(P.cs4);
+}
+
 // populations -> moments (LBM_d3q19.H:100-156)
 __device__ __forceinline__ void d_moments(const double (&fs)[Q], double (&m)[Q]) {
   double f;
@@ -268,19 +294,21 @@ struct SiteHydro {
 __device__ __forceinline__ void d_hydrovars_j(const DevParams& P, const double (&jf)[3], const double (&jg)[3],
                                               double rho, double phi,
                                               const double (&grad_rho)[3], const double (&grad_phi)[3],
-                                              const double (&nf)[Q], const double (&ng)[Q], SiteHydro& H) {
+                                              const double (&nf)[Q], const double (&ng)[Q], SiteHydro& H,
+                                              const SiteRecip& R) {
   const bool okr = fabs(rho) > (double)FLT_EPSILON;
   const bool okp = fabs(phi) > (double)FLT_EPSILON;
-  const double wphi = P.kf*phi/(rho+phi);
-  const double wrho = P.kg*rho/(rho+phi);
+  const double tot = rho + phi;
+  const double wphi = d_div(P.kf*phi, tot, R.tot);
+  const double wrho = d_div(P.kg*rho, tot, R.tot);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    H.ufbar[k] = okr ? jf[k]/rho : 0.;
-    H.ugbar[k] = okp ? jg[k]/phi : 0.;
-    H.af[k] = okr ? P.neg_cs2_alpha0*rho*grad_phi[k]/rho : 0.;
-    H.ag[k] = okp ? P.neg_cs2_alpha0*phi*grad_rho[k]/phi : 0.;
-    H.nfvel[k] = okr ? nf[1+k]/rho : 0.;
-    H.ngvel[k] = okp ? ng[1+k]/phi : 0.;
+    H.ufbar[k] = okr ? d_div(jf[k], rho, R.rho) : 0.;
+    H.ugbar[k] = okp ? d_div(jg[k], phi, R.phi) : 0.;
+    H.af[k] = okr ? d_div(P.neg_cs2_alpha0*rho*grad_phi[k], rho, R.rho) : 0.;
+    H.ag[k] = okp ? d_div(P.neg_cs2_alpha0*phi*grad_rho[k], phi, R.phi) : 0.;
+    H.nfvel[k] = okr ? d_div(nf[1+k], rho, R.rho) : 0.;
+    H.ngvel[k] = okp ? d_div(ng[1+k], phi, R.phi) : 0.;
     H.uf[k] = H.ufbar[k] + 0.5*H.af[k] - wphi*(H.ufbar[k]-H.ugbar[k] + 0.5*(H.af[k]-H.ag[k])) + 0.5*H.nfvel[k];
     H.ug[k] = H.ugbar[k] + 0.5*H.ag[k] - wrho*(H.ugbar[k]-H.ufbar[k] + 0.5*(H.ag[k]-H.af[k])) + 0.5*H.ngvel[k];
   }
@@ -289,21 +317,22 @@ __device__ __forceinline__ void d_hydrovars_j(const DevParams& P, const double (
 __device__ __forceinline__ void d_hydrovars(const DevParams& P, const double (&fs)[Q], const double (&gs)[Q],
                                             double rho, double phi,
                                             const double (&grad_rho)[3], const double (&grad_phi)[3],
-                                            const double (&nf)[Q], const double (&ng)[Q], SiteHydro& H) {
+                                            const double (&nf)[Q], const double (&ng)[Q], SiteHydro& H,
+                                            const SiteRecip& R) {
   double jf[3], jg[3];
   d_momentum(fs, jf);
   d_momentum(gs, jg);
-  d_hydrovars_j(P, jf, jg, rho, phi, grad_rho, grad_phi, nf, ng, H);
+  d_hydrovars_j(P, jf, jg, rho, phi, grad_rho, grad_phi, nf, ng, H, R);
 }
 
 // equilibrium_moments (LBM_binary.H:356-402): only modes 0..9 are non-zero.
-__device__ __forceinline__ void d_equilibrium(const DevParams& P, double rho, const double (&u)[3], double (&mEq)[10]) {
-  const double A00 = (rho*u[0]*u[0])/2./P.cs4;
-  const double A01 = (rho*u[0]*u[1])/2./P.cs4;
-  const double A02 = (rho*u[0]*u[2])/2./P.cs4;
-  const double A11 = (rho*u[1]*u[1])/2./P.cs4;
-  const double A12 = (rho*u[1]*u[2])/2./P.cs4;
-  const double A22 = (rho*u[2]*u[2])/2./P.cs4;
+__device__ __forceinline__ void d_equilibrium(const DevParams& P, double rho, const double (&u)[3], double (&mEq)[10], double ycs4) {
+  const double A00 = d_div((rho*u[0]*u[0])/2., P.cs4, ycs4);
+  const double A01 = d_div((rho*u[0]*u[1])/2., P.cs4, ycs4);
+  const double A02 = d_div((rho*u[0]*u[2])/2., P.cs4, ycs4);
+  const double A11 = d_div((rho*u[1]*u[1])/2., P.cs4, ycs4);
+  const double A12 = d_div((rho*u[1]*u[2])/2., P.cs4, ycs4);
+  const double A22 = d_div((rho*u[2]*u[2])/2., P.cs4, ycs4);
   const double tr = A00 + A11 + A22;
   mEq[0] = rho*1.;
   mEq[1] = P.coefC_cs2*(rho*u[0]);
@@ -318,12 +347,12 @@ __device__ __forceinline__ void d_equilibrium(const DevParams& P, double rho, co
 }
 
 // phi_moments (LBM_binary.H:404-449)
-__device__ __forceinline__ void d_force_moments(const DevParams& P, double rho, const double (&u)[3], const double (&a)[3], double (&mPhi)[10]) {
+__device__ __forceinline__ void d_force_moments(const DevParams& P, double rho, const double (&u)[3], const double (&a)[3], double (&mPhi)[10], double ycs4) {
   const double coefAC = rho*P.coefC;
   double ru[3] = { rho*u[0], rho*u[1], rho*u[2] };
-  const double A00 = a[0]*ru[0]/P.cs4, A01 = a[0]*ru[1]/P.cs4, A02 = a[0]*ru[2]/P.cs4;
-  const double A10 = a[1]*ru[0]/P.cs4, A11 = a[1]*ru[1]/P.cs4, A12 = a[1]*ru[2]/P.cs4;
-  const double A20 = a[2]*ru[0]/P.cs4, A21 = a[2]*ru[1]/P.cs4, A22 = a[2]*ru[2]/P.cs4;
+  const double A00 = d_div(a[0]*ru[0], P.cs4, ycs4), A01 = d_div(a[0]*ru[1], P.cs4, ycs4), A02 = d_div(a[0]*ru[2], P.cs4, ycs4);
+  const double A10 = d_div(a[1]*ru[0], P.cs4, ycs4), A11 = d_div(a[1]*ru[1], P.cs4, ycs4), A12 = d_div(a[1]*ru[2], P.cs4, ycs4);
+  const double A20 = d_div(a[2]*ru[0], P.cs4, ycs4), A21 = d_div(a[2]*ru[1], P.cs4, ycs4), A22 = d_div(a[2]*ru[2], P.cs4, ycs4);
   const double tr = A00 + A11 + A22;
   mPhi[0] = P.modifactor*(rho*0.);
   mPhi[1] = P.modifactor*coefAC*P.cs2*a[0];
@@ -343,10 +372,10 @@ __device__ __forceinline__ void d_force_moments(const DevParams& P, double rho, 
 template <bool NOISE>
 __device__ __forceinline__ void d_relax(const DevParams& P, double (&m)[Q], double rho_k, const double (&v_b)[3],
                                         const double (&u)[3], const double (&a)[3], double inv_tau_bar,
-                                        const double (&noise)[Q]) {
+                                        const double (&noise)[Q], double ycs4) {
   double mEq[10], mPhi[10];
-  d_equilibrium(P, rho_k, v_b, mEq);
-  d_force_moments(P, rho_k, u, a, mPhi);
+  d_equilibrium(P, rho_k, v_b, mEq, ycs4);
+  d_force_moments(P, rho_k, u, a, mPhi, ycs4);
 #pragma unroll
   for (int k = 0; k < 10; ++k) {
     double R = inv_tau_bar*(mEq[k] - m[k]) + mPhi[k];
@@ -361,9 +390,9 @@ __device__ __forceinline__ void d_relax(const DevParams& P, double (&m)[Q], doub
   }
 }
 
-__device__ __forceinline__ void d_barycentric(double rho, double phi, const SiteHydro& H, double (&v_b)[3]) {
+__device__ __forceinline__ void d_barycentric(double rho, double phi, const SiteHydro& H, double (&v_b)[3], const SiteRecip& R) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) v_b[k] = (rho*H.uf[k] + phi*H.ug[k])/(rho + phi);   // LBM_binary.H:471
+  for (int k = 0; k < 3; ++k) v_b[k] = d_div(rho*H.uf[k] + phi*H.ug[k], rho + phi, R.tot);   // LBM_binary.H:471
 }
 
 // collide (LBM_binary.H:451-516): fs,gs are replaced by the post-collision populations.
@@ -371,19 +400,19 @@ __device__ __forceinline__ void d_barycentric(double rho, double phi, const Site
 template <bool NOISE>
 __device__ __forceinline__ void d_collide(const DevParams& P, double (&fs)[Q], double (&gs)[Q],
                                           double rho, double phi, const SiteHydro& H,
-                                          const double (&fn)[Q], const double (&gn)[Q]) {
+                                          const double (&fn)[Q], const double (&gn)[Q], const SiteRecip& R) {
   double v_b[3];
-  d_barycentric(rho, phi, H, v_b);
+  d_barycentric(rho, phi, H, v_b, R);
   {
     double m[Q];
     d_moments(fs, m);
-    d_relax<NOISE>(P, m, rho, v_b, H.uf, H.af, P.inv_tau_f_bar, fn);
+    d_relax<NOISE>(P, m, rho, v_b, H.uf, H.af, P.inv_tau_f_bar, fn, R.cs4);
     d_populations(m, fs);
   }
   {
     double m[Q];
     d_moments(gs, m);
-    d_relax<NOISE>(P, m, phi, v_b, H.ug, H.ag, P.inv_tau_g_bar, gn);
+    d_relax<NOISE>(P, m, phi, v_b, H.ug, H.ag, P.inv_tau_g_bar, gn, R.cs4);
     d_populations(m, gs);
   }
 }

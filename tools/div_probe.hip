@@ -20,6 +20,13 @@ __global__ void k(unsigned long long* bad, unsigned long long seed, int rounds) 
     if (d_div9(x) * 0.25 != x / 36.0) ++nb;
     if (d_div3(x) * 0.0625 != x / 48.0) ++nb;
     if (d_div9(x) * 0.125 != x / 72.0) ++nb;
+    // shared-reciprocal division against a/b: denominators in [2^-40, 2^40], cs4 exactly
+    unsigned long long s2 = s * 0x9E3779B97F4A7C15ull + r;
+    long long eb = 1023 + (long long)((s2 >> 52) % 81) - 40;
+    double b = __longlong_as_double((long long)(((unsigned long long)eb << 52) | (s2 & 0xFFFFFFFFFFFFFull)));
+    if (d_div(x, b, d_recip(b)) != x / b) ++nb;
+    const double cs4 = (1. / 3.) * (1. / 3.);
+    if (d_div(x, cs4, d_recip(cs4)) != x / cs4) ++nb;
   }
   if (nb) atomicAdd(bad, nb);
 }
@@ -28,6 +35,6 @@ int main() {
   const int blocks = 4096, threads = 256, rounds = 4096;   // 2^32 samples
   k<<<blocks, threads>>>(d, 12345, rounds);
   unsigned long long h = 1; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
-  printf("div_probe: %llu mismatches in %llu samples x 5 forms\n", h, (unsigned long long)blocks * threads * rounds);
+  printf("div_probe: %llu mismatches in %llu samples x 7 forms\n", h, (unsigned long long)blocks * threads * rounds);
   return h != 0;
 }
