@@ -81,6 +81,7 @@ struct bflbm_ctx {
   Geo G;
   int nzl = 0;
   double* S[2] = {nullptr, nullptr};
+  double* S_alloc[2] = {nullptr, nullptr};
   int cur = 0;
   double* rho = nullptr;
   double* phi = nullptr;
@@ -265,11 +266,21 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   G.nzs = c->nzl + 2 * G.H;
   G.z0 = d->z0;
   G.plane = (long long)G.nx * G.ny;
-  G.vol = G.plane * G.nzs;
+  // component stride: padded by 65 cache lines so that the 38 component arrays of a power-of-two
+  // lattice do not all start on the same memory channel / L2 set.  Measured on MI355X (256^3):
+  // pull-copy 1.96 -> 1.77 ms, fused step 2.57 -> 2.35 ms (BFLBM_PAD = doubles, tuning override).
+  static const long long pad = [] { const char* e = getenv("BFLBM_PAD"); return e ? atoll(e) : 1040LL; }();
+  G.vol = G.plane * G.nzs + pad;
   const size_t sbytes = (size_t)2 * Q * G.vol * sizeof(double);
   const size_t fbytes = (size_t)G.vol * sizeof(double);
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipMalloc((void**)&c->S[k], sbytes);
+  // the B buffer is additionally shifted against the A buffer (BFLBM_PAD_AB doubles, tuning override)
+  static const long long pad_ab = [] { const char* e2 = getenv("BFLBM_PAD_AB"); return e2 ? atoll(e2) : 0LL; }();
+  c->S_alloc[0] = c->S_alloc[1] = nullptr;
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    e = hipMalloc((void**)&c->S_alloc[k], sbytes + (size_t)pad_ab * sizeof(double));
+    c->S[k] = c->S_alloc[k] ? c->S_alloc[k] + (k == 1 ? pad_ab : 0) : nullptr;
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&c->rho, fbytes);
   if (e == hipSuccess) e = hipMalloc((void**)&c->phi, fbytes);
   c->partial_n = (size_t)((G.plane + 255) / 256) * (size_t)c->nzl;
@@ -297,7 +308,7 @@ int bflbm_destroy(bflbm_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->dom.device);
   if (c->stream && c->own_stream) hipStreamSynchronize(c->stream);
-  for (int k = 0; k < 2; ++k) if (c->S[k]) hipFree(c->S[k]);
+  for (int k = 0; k < 2; ++k) if (c->S_alloc[k]) hipFree(c->S_alloc[k]);
   if (c->rho) hipFree(c->rho);
   if (c->phi) hipFree(c->phi);
   if (c->injf) hipFree(c->injf);
@@ -674,6 +685,14 @@ int bflbm_debug_time_kernel(bflbm_ctx* c, int which, int reps, float* ms) {
   c->density_valid = false;
   return 0;
 }
+
+#ifdef BFLBM_STAMP
+extern "C" int bflbm_debug_stamps(unsigned long long* out, int max_waves) {   // diagnostic builds only
+  int n = g_stamp_n < max_waves ? g_stamp_n : max_waves;
+  if (g_stamp_buf && n > 0) hipMemcpy(out, g_stamp_buf, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  return n;
+}
+#endif
 
 int bflbm_device_bytes(const bflbm_ctx* c, size_t* bytes) {
   if (!c || !bytes) return fail("null argument");

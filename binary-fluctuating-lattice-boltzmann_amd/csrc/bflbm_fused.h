@@ -31,6 +31,7 @@ struct FusedGrid {
   int ncols;           // ntx*nty
   int total;           // ncols*nchunks workgroups
   int per_xcd;         // ceil(total/8)
+  unsigned long long* dbg;   // BFLBM_STAMP diagnostic builds only: per-workgroup phase cycle sums
 };
 
 // Workgroup -> (column, chunk).  Workgroups b and b+8 share an XCD (round-robin dispatch), so give
@@ -48,6 +49,20 @@ __device__ __forceinline__ bool fused_map(const FusedGrid& F, int b, int& col, i
   return true;
 }
 
+#ifdef BFLBM_STAMP
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+#ifndef BFLBM_NT_STORE
+#define BFLBM_NT_STORE 0
+#endif
+#if BFLBM_NT_STORE
+#define BFLBM_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define BFLBM_STORE(p, v) (*(p) = (v))
+#endif
 #ifndef BFLBM_ABL
 #define BFLBM_ABL 0   // ablation switches for timing experiments only (results become wrong)
 #endif
@@ -122,9 +137,14 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #pragma unroll
   for (int i = 0; i < Q; ++i) pf[i] = 0.;
 
+#ifdef BFLBM_STAMP
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
   int it = 0;
   for (int q = qa - 1; q <= qb; ++q, ++it) {
     const int slot = it & 3;
+    STAMP(5);
     // wave-uniform plane bases: every load below is  (SGPR base) + (32-bit lane offset)
     const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
                                          S + (long long)wrapp(q + 1) * G.plane };
@@ -153,10 +173,13 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #pragma unroll
       for (int i = 0; i < Q; ++i) { cf[i] = 0.; cg[i] = 0.; }
     }
+    STAMP(0);                                   // loads issued
     // 2. densities of plane q into the ring slot
     if (has_task) rp[slot][hfl][lhalo] = d_density(hv);
     if (loader) { rp[slot][0][lown] = d_density(cf); rp[slot][1][lown] = d_density(cg); }
+    STAMP(1);                                   // data arrived, sums done
     __syncthreads();
+    STAMP(2);                                   // barrier
     // 3. collide plane q-1: f from registers, g streamed out of LDS while plane q's g takes its place
     const bool do_collide = (q - 1 >= qa) && (q - 1 < qb) && interior;
     double mg[Q], jg[3];
@@ -214,20 +237,28 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
           double out[Q];
           d_populations(mf, out);
 #pragma unroll
-          for (int i = 0; i < Q; ++i) Dp[(long long)i * G.vol + o] = out[i];
+          for (int i = 0; i < Q; ++i) BFLBM_STORE(&Dp[(long long)i * G.vol + o], out[i]);
         }
         {
           d_relax<MODE != 0>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn, R.cs4);
           double out[Q];
           d_populations(mg, out);
 #pragma unroll
-          for (int i = 0; i < Q; ++i) Dp[(long long)(i + Q) * G.vol + o] = out[i];
+          for (int i = 0; i < Q; ++i) BFLBM_STORE(&Dp[(long long)(i + Q) * G.vol + o], out[i]);
         }
       }
     }
+    STAMP(3);                                   // collide + stores issued
 #pragma unroll
     for (int i = 0; i < Q; ++i) pf[i] = cf[i];
   }
+#ifdef BFLBM_STAMP
+  if (F.dbg && (tid & 63) == 0) {
+    unsigned long long* o = F.dbg + ((long long)blockIdx.x * (TX * TY / 64) + (tid >> 6)) * 8;
+    for (int k = 0; k < 6; ++k) o[k] = tacc[k];
+    o[6] = (unsigned long long)it; o[7] = __builtin_amdgcn_s_memtime();
+  }
+#endif
 }
 
 #ifndef BFLBM_FUSED_TX
@@ -237,6 +268,10 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #define BFLBM_FUSED_TY 8
 #endif
 
+#ifdef BFLBM_STAMP
+static unsigned long long* g_stamp_buf = nullptr;
+static int g_stamp_n = 0;
+#endif
 // returns non-zero on launch failure
 static inline int fused_launch(const double* S, double* D, const double* injf, const double* injg,
                                const Geo& G, const DevParams& P, int pa, int pb,
@@ -259,6 +294,10 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   F.nchunks = (np + F.lz - 1) / F.lz;
   F.total = F.ncols * F.nchunks;
   F.per_xcd = (F.total + 7) / 8;
+  F.dbg = nullptr;
+#ifdef BFLBM_STAMP
+  { static unsigned long long* dbuf = nullptr; if (!dbuf) hipMalloc(&dbuf, 8192 * 16 * 8 * sizeof(unsigned long long)); F.dbg = dbuf; g_stamp_buf = dbuf; g_stamp_n = F.per_xcd * 8 * (TX * TY / 64); }
+#endif
   dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
   if (mode == 2)      hipLaunchKernelGGL((k_fused<TX, TY, 2>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
   else if (mode == 1) hipLaunchKernelGGL((k_fused<TX, TY, 1>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
