@@ -206,19 +206,24 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
       for (int i = 0; i < Q; ++i) nb[i] = rp[sl[1 + Vel::cz[i]]][1][lown + Vel::cy[i] * LW + Vel::cx[i]];
       d_gradient(P, nb, grad_phi);
       const int pc = wrapp(q - 1);
-      double fn[Q], gn[Q];
+      // noise: momentum modes now (hydrovars needs them), the rest right before each relaxation
+      double fn3[3] = {0., 0., 0.}, gn3[3] = {0., 0., 0.};
+      NoiseAmp NA; float n3 = 0.f; uint64_t site = 0;
+      const double* __restrict__ nb_f = nullptr; const double* __restrict__ nb_g = nullptr;
+      long long nvol = 0; unsigned no = 0;
       if (MODE == 2) {
-        const long long nvol = (long long)(G.nzs - 2 * G.H) * G.plane;
-        const double* __restrict__ nb_f = injf + (long long)(pc - G.H) * G.plane;
-        const double* __restrict__ nb_g = injg + (long long)(pc - G.H) * G.plane;
-        const unsigned no = yo[1] + xo[1];
+        nvol = (long long)(G.nzs - 2 * G.H) * G.plane;
+        nb_f = injf + (long long)(pc - G.H) * G.plane;
+        nb_g = injg + (long long)(pc - G.H) * G.plane;
+        no = yo[1] + xo[1];
 #pragma unroll
-        for (int a = 0; a < Q; ++a) { fn[a] = nb_f[a * nvol + no]; gn[a] = nb_g[a * nvol + no]; }
+        for (int k = 0; k < 3; ++k) { fn3[k] = nb_f[(1 + k) * nvol + no]; gn3[k] = nb_g[(1 + k) * nvol + no]; }
       } else if (MODE == 1) {
-        d_noise(P, r, ph, global_site(G, x, y, pc), noise_index, fn, gn);
-      } else {
+        site = global_site(G, x, y, pc);
+        d_noise_amp(P, r, ph, NA);
+        d_noise_head(P, NA, site, noise_index, fn3, n3);
 #pragma unroll
-        for (int a = 0; a < Q; ++a) { fn[a] = 0.; gn[a] = 0.; }
+        for (int k = 0; k < 3; ++k) gn3[k] = -fn3[k];
       }
       double* __restrict__ Dp = D + (long long)pc * G.plane;
       const unsigned o = yo[1] + xo[1];
@@ -229,10 +234,20 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
         SiteHydro Hy;
         SiteRecip R;
         d_site_recips(P, r, ph, R);
-        d_hydrovars_j(P, jf, jg, r, ph, grad_rho, grad_phi, fn, gn, Hy, R);
+        d_hydrovars_j(P, jf, jg, r, ph, grad_rho, grad_phi, fn3, gn3, Hy, R);
         double v_b[3];
         d_barycentric(r, ph, Hy, v_b, R);
         {
+          double fn[Q];
+          if (MODE == 2) {
+#pragma unroll
+            for (int a = 0; a < Q; ++a) fn[a] = nb_f[a * nvol + no];
+          } else if (MODE == 1) {
+            d_noise_f(P, NA, site, noise_index, fn3, n3, fn);
+          } else {
+#pragma unroll
+            for (int a = 0; a < Q; ++a) fn[a] = 0.;
+          }
           d_relax<MODE != 0>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn, R.cs4);
           double out[Q];
           d_populations(mf, out);
@@ -240,6 +255,16 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
           for (int i = 0; i < Q; ++i) BFLBM_STORE(&Dp[(long long)i * G.vol + o], out[i]);
         }
         {
+          double gn[Q];
+          if (MODE == 2) {
+#pragma unroll
+            for (int a = 0; a < Q; ++a) gn[a] = nb_g[a * nvol + no];
+          } else if (MODE == 1) {
+            d_noise_g(P, NA, site, noise_index, fn3, gn);
+          } else {
+#pragma unroll
+            for (int a = 0; a < Q; ++a) gn[a] = 0.;
+          }
           d_relax<MODE != 0>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn, R.cs4);
           double out[Q];
           d_populations(mg, out);

@@ -260,27 +260,61 @@ __device__ __forceinline__ void d_gradient(const DevParams& P, const double (&nb
   g[0] = gx; g[1] = gy; g[2] = gz;
 }
 
-// thermal_noise (LBM_binary.H:73-132) for one site: 3 + 2*15 draws in the reference's order.
+// thermal_noise (LBM_binary.H:73-132) for one site.  The amplitude of mode a >= 4 is
+// sqrt(amp[a]*|rho|) with amp[a] proportional to the mode norm b[a]; b takes only six distinct
+// values (2/3, 4/3, 4/9, 1/9, 2/9, 2; LBM_d3q19.H:56-76), so 6 square roots per fluid give the
+// same doubles as the reference's 15.  Normals: blocks 0..4 of the site's stream feed fluid f
+// (and the shared momentum modes), blocks 5..8 fluid g, so each fluid's noise can be generated
+// right before its relaxation.
+struct NoiseAmp { double sj, sf[6], sg[6]; };
+__device__ __forceinline__ int d_noise_group(int a) {   // modes 4..18 -> index of b[a] among the six values
+  return (a == 4 || (a >= 10 && a <= 12)) ? 0 : (a == 5 || a == 17) ? 1 : (a == 6 || a == 18) ? 2
+       : (a >= 7 && a <= 9) ? 3 : (a >= 13 && a <= 15) ? 4 : 5;
+}
+__device__ __forceinline__ void d_noise_amp(const DevParams& P, double rho, double phi, NoiseAmp& A) {
+  const double rhot = rho + phi;
+  A.sj = sqrt(P.amp_j * fabs(rho*phi/rhot));
+  const double arho = fabs(rho), aphi = fabs(phi);
+  const int rep[6] = {4, 5, 6, 7, 13, 16};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { A.sf[k] = sqrt(P.amp_f[rep[k]] * arho); A.sg[k] = sqrt(P.amp_g[rep[k]] * aphi); }
+}
+// momentum-mode noise (modes 1..3 of f; g gets the negative) and the normal of f mode 4
+__device__ __forceinline__ void d_noise_head(const DevParams& P, const NoiseAmp& A, uint64_t site, uint32_t idx,
+                                             double (&fn3)[3], float& n3) {
+  float n0, n1, n2;
+  bflbm_rng_block(P.seed_lo, P.seed_hi, site, idx, 0u, n0, n1, n2, n3);
+  fn3[0] = A.sj * (double)n0; fn3[1] = A.sj * (double)n1; fn3[2] = A.sj * (double)n2;
+}
+__device__ __forceinline__ void d_noise_f(const DevParams& P, const NoiseAmp& A, uint64_t site, uint32_t idx,
+                                          const double (&fn3)[3], float n3, double (&fn)[Q]) {
+  float nrm[20];
+  nrm[3] = n3;
+#pragma unroll
+  for (uint32_t blk = 1; blk < 5; ++blk)
+    bflbm_rng_block(P.seed_lo, P.seed_hi, site, idx, blk, nrm[4*blk], nrm[4*blk+1], nrm[4*blk+2], nrm[4*blk+3]);
+  fn[0] = 0.; fn[1] = fn3[0]; fn[2] = fn3[1]; fn[3] = fn3[2];
+#pragma unroll
+  for (int a = 4; a < Q; ++a) fn[a] = A.sf[d_noise_group(a)] * (double)nrm[3 + (a-4)];
+}
+__device__ __forceinline__ void d_noise_g(const DevParams& P, const NoiseAmp& A, uint64_t site, uint32_t idx,
+                                          const double (&fn3)[3], double (&gn)[Q]) {
+  float nrm[16];
+#pragma unroll
+  for (uint32_t blk = 5; blk < 9; ++blk)
+    bflbm_rng_block(P.seed_lo, P.seed_hi, site, idx, blk, nrm[4*(blk-5)], nrm[4*(blk-5)+1], nrm[4*(blk-5)+2], nrm[4*(blk-5)+3]);
+  gn[0] = 0.; gn[1] = -fn3[0]; gn[2] = -fn3[1]; gn[3] = -fn3[2];
+#pragma unroll
+  for (int a = 4; a < Q; ++a) gn[a] = A.sg[d_noise_group(a)] * (double)nrm[a-4];
+}
+// all 38 noise moments (two-pass schedule, observables)
 __device__ __forceinline__ void d_noise(const DevParams& P, double rho, double phi, uint64_t site,
                                         uint32_t noise_index, double (&fn)[Q], double (&gn)[Q]) {
-  float nrm[36];
-#pragma unroll
-  for (uint32_t blk = 0; blk < 9; ++blk)
-    bflbm_rng_block(P.seed_lo, P.seed_hi, site, noise_index, blk, nrm[4*blk], nrm[4*blk+1], nrm[4*blk+2], nrm[4*blk+3]);
-  const double rhot = rho + phi;
-  fn[0] = 0.; gn[0] = 0.;
-  const double sj = sqrt(P.amp_j * fabs(rho*phi/rhot));
-#pragma unroll
-  for (int a = 1; a <= 3; ++a) {
-    fn[a] = sj * (double)nrm[a-1];
-    gn[a] = -fn[a];
-  }
-  const double arho = fabs(rho), aphi = fabs(phi);
-#pragma unroll
-  for (int a = 4; a < Q; ++a) {
-    fn[a] = sqrt(P.amp_f[a] * arho) * (double)nrm[3 + 2*(a-4)];
-    gn[a] = sqrt(P.amp_g[a] * aphi) * (double)nrm[4 + 2*(a-4)];
-  }
+  NoiseAmp A; d_noise_amp(P, rho, phi, A);
+  double fn3[3]; float n3;
+  d_noise_head(P, A, site, noise_index, fn3, n3);
+  d_noise_f(P, A, site, noise_index, fn3, n3, fn);
+  d_noise_g(P, A, site, noise_index, fn3, gn);
 }
 
 // The quantities hydrovars() derives per site (LBM_binary.H:196-295) that collide() consumes.
@@ -294,7 +328,7 @@ struct SiteHydro {
 __device__ __forceinline__ void d_hydrovars_j(const DevParams& P, const double (&jf)[3], const double (&jg)[3],
                                               double rho, double phi,
                                               const double (&grad_rho)[3], const double (&grad_phi)[3],
-                                              const double (&nf)[Q], const double (&ng)[Q], SiteHydro& H,
+                                              const double (&nf3)[3], const double (&ng3)[3], SiteHydro& H,
                                               const SiteRecip& R) {
   const bool okr = fabs(rho) > (double)FLT_EPSILON;
   const bool okp = fabs(phi) > (double)FLT_EPSILON;
@@ -307,8 +341,8 @@ __device__ __forceinline__ void d_hydrovars_j(const DevParams& P, const double (
     H.ugbar[k] = okp ? d_div(jg[k], phi, R.phi) : 0.;
     H.af[k] = okr ? d_div(P.neg_cs2_alpha0*rho*grad_phi[k], rho, R.rho) : 0.;
     H.ag[k] = okp ? d_div(P.neg_cs2_alpha0*phi*grad_rho[k], phi, R.phi) : 0.;
-    H.nfvel[k] = okr ? d_div(nf[1+k], rho, R.rho) : 0.;
-    H.ngvel[k] = okp ? d_div(ng[1+k], phi, R.phi) : 0.;
+    H.nfvel[k] = okr ? d_div(nf3[k], rho, R.rho) : 0.;
+    H.ngvel[k] = okp ? d_div(ng3[k], phi, R.phi) : 0.;
     H.uf[k] = H.ufbar[k] + 0.5*H.af[k] - wphi*(H.ufbar[k]-H.ugbar[k] + 0.5*(H.af[k]-H.ag[k])) + 0.5*H.nfvel[k];
     H.ug[k] = H.ugbar[k] + 0.5*H.ag[k] - wrho*(H.ugbar[k]-H.ufbar[k] + 0.5*(H.ag[k]-H.af[k])) + 0.5*H.ngvel[k];
   }
@@ -322,7 +356,8 @@ __device__ __forceinline__ void d_hydrovars(const DevParams& P, const double (&f
   double jf[3], jg[3];
   d_momentum(fs, jf);
   d_momentum(gs, jg);
-  d_hydrovars_j(P, jf, jg, rho, phi, grad_rho, grad_phi, nf, ng, H, R);
+  const double nf3[3] = { nf[1], nf[2], nf[3] }, ng3[3] = { ng[1], ng[2], ng[3] };
+  d_hydrovars_j(P, jf, jg, rho, phi, grad_rho, grad_phi, nf3, ng3, H, R);
 }
 
 // equilibrium_moments (LBM_binary.H:356-402): only modes 0..9 are non-zero.

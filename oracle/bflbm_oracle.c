@@ -318,7 +318,7 @@ void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
 
 /* ------------------------------------------------------------------ */
 /* thermal_noise, LBM_binary.H:73-132 (non-USE_REF_STATE branch, :109-111).
- * Draw order per site: modes 1..3, then (f,g) interleaved for modes 4..18.
+ * Draw count per site as in the reference: 3 + 2*15 normals.
  * gz0 = global z of local plane 0 and gnz = global nz (slab tests; the site id that keys the
  * random stream is the GLOBAL lattice index). */
 void orc_thermal_noise_slab(const orc_params* p, int nx, int ny, int nz, int gz0, int gnz,
@@ -337,17 +337,20 @@ void orc_thermal_noise_slab(const orc_params* p, int nx, int ny, int nz, int gz0
     int gz = (z + gz0) % gnz; if (gz < 0) gz += gnz;
     uint64_t site = (uint64_t)x + (uint64_t)nx*((uint64_t)y + (uint64_t)ny*(uint64_t)gz);
     orc_site_normals(p->seed, site, noise_index, nrm);
-    int d = 0;
+    /* Assignment of the site's normals to modes (project-defined, like the stream itself):
+     * nrm[0..2] -> momentum modes 1..3 (gn = -fn), nrm[3 + (a-4)] -> f mode a (blocks 0..4),
+     * nrm[20 + (a-4)] -> g mode a (blocks 5..8); a = 4..18.  The reference interleaves f,g draws
+     * (:124-127), which is immaterial for an i.i.d. stream. */
     fn[IDX(nx,ny,nz,0,x,y,z)] = 0.;
     gn[IDX(nx,ny,nz,0,x,y,z)] = 0.;
     for (int a = 1; a <= 3; a++) {
-      double v = sqrt(2.*(tau_f_bar - 0.5*tau_f_bar2)*kBT*fabs(rho*phi/rhot))*nrm[d++];
+      double v = sqrt(2.*(tau_f_bar - 0.5*tau_f_bar2)*kBT*fabs(rho*phi/rhot))*nrm[a-1];
       fn[IDX(nx,ny,nz,a,x,y,z)] = v;
       gn[IDX(nx,ny,nz,a,x,y,z)] = -v;
     }
     for (int a = 4; a < Q; a++) {
-      fn[IDX(nx,ny,nz,a,x,y,z)] = sqrt(2.*(tau_f_bar - 0.5*tau_f_bar2)*kBT/cs2*B[a]*fabs(rho))*nrm[d++];
-      gn[IDX(nx,ny,nz,a,x,y,z)] = sqrt(2.*(tau_g_bar - 0.5*tau_g_bar2)*kBT/cs2*B[a]*fabs(phi))*nrm[d++];
+      fn[IDX(nx,ny,nz,a,x,y,z)] = sqrt(2.*(tau_f_bar - 0.5*tau_f_bar2)*kBT/cs2*B[a]*fabs(rho))*nrm[3 + (a-4)];
+      gn[IDX(nx,ny,nz,a,x,y,z)] = sqrt(2.*(tau_g_bar - 0.5*tau_g_bar2)*kBT/cs2*B[a]*fabs(phi))*nrm[20 + (a-4)];
     }
   }
 }
