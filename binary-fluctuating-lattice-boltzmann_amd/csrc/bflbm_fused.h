@@ -310,7 +310,11 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   const int np = pb - pa;
   // enough chunks to fill the chip a few times over (2 workgroups resident per CU), chunks of
   // >= 16 planes; BFLBM_FUSED_WG overrides the target workgroup count (tuning only)
-  static const int want = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 512; }();
+  static const int want_env = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 0; }();
+  // Single slab: 512 workgroups (two rounds of one 512-thread workgroup per CU).  Slab of a
+  // multi-GPU run: 1024 shorter ones, so that the RCCL copy kernels of the overlapped exchange,
+  // which need a few CUs of their own, delay at most a short tail of the interior sweep.
+  const int want = want_env > 0 ? want_env : (G.zwrap ? 512 : 1024);
   int nchunks = (want + F.ncols - 1) / F.ncols;
   const int maxchunks = (np + 15) / 16;
   if (nchunks > maxchunks) nchunks = maxchunks;
