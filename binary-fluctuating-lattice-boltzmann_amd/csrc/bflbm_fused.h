@@ -126,9 +126,10 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   // ---- chunk of planes
   const int qa = F.pa + chunk * F.lz;
   const int qb = min(F.pb, qa + F.lz);
-  auto wrapp = [&](int q) {
+  auto wrapp = [&](int q) {                      // q in [-2, nzs+1]; nzs may be 1, so use a true modulo
     if (!G.zwrap) return q;
-    return q < 0 ? q + G.nzs : (q >= G.nzs ? q - G.nzs : q);
+    const int m = q % G.nzs;
+    return m < 0 ? m + G.nzs : m;
   };
 
   // Held across one march position: f of the previous plane in registers, g of the previous

@@ -161,6 +161,28 @@ __global__ void __launch_bounds__(256) k_pull(const double* __restrict__ S, doub
   }
 }
 
+// calibration only: the same pull-copy with two x-adjacent sites per thread (16-byte accesses where aligned)
+__global__ void __launch_bounds__(256) k_pull2(const double* __restrict__ S, double* __restrict__ N, Geo G, int p0) {
+  const long long s_ = ((long long)blockIdx.x*blockDim.x + threadIdx.x) * 2;
+  if (s_ >= G.plane) return;
+  const int p = p0 + (int)blockIdx.y;
+  const int y = (int)(s_ / G.nx);
+  const int x = (int)(s_ - (long long)y*G.nx);
+  SiteIdx I; site_index(G, x, y, p, I);
+  const long long o = I.row[1][1] + x;
+#pragma unroll
+  for (int i = 0; i < 2*Q; ++i) {
+    const int k = i % Q;
+    const long long r = I.row[1 - Vel::cz[k]][1 - Vel::cy[k]];
+    const double* __restrict__ src = S + (long long)i*G.vol + r;
+    double2 v;
+    if (Vel::cx[k] == 0) v = *reinterpret_cast<const double2*>(src + x);
+    else if (Vel::cx[k] > 0) { v.x = src[I.xm]; v.y = src[x]; }
+    else { v.x = src[x + 1]; v.y = src[(x + 2 >= G.nx) ? x + 2 - G.nx : x + 2]; }
+    *reinterpret_cast<double2*>(N + (long long)i*G.vol + o) = v;
+  }
+}
+
 // ---- inverse: S_i(x) = N_i(x + c_i)  (upload of fold/gold, LBM_binary.H:643)
 __global__ void __launch_bounds__(256) k_unstream(const double* __restrict__ N, double* __restrict__ S, Geo G, int p0) {
   BFLBM_SITE_FROM_BLOCK();

@@ -71,6 +71,30 @@ def test_zero_noise_steps_bit_exact(pkg, ob, dims, init, steps, schedule):
     lbm.close()
 
 
+@pytest.mark.parametrize("schedule", SCHEDULES)
+@pytest.mark.parametrize("dims", [(1, 1, 8), (2, 2, 2), (1, 9, 1), (3, 5, 4), (65, 9, 3), (64, 8, 2), (130, 17, 5), (127, 7, 3), (2, 1, 1)])
+def test_degenerate_and_tile_edge_sizes(pkg, ob, dims, schedule):
+    """Periodic wrap with 1- and 2-wide directions (a site is its own neighbour) and sizes straddling
+    the 64x8 tile of the fused kernel."""
+    rng = np.random.default_rng(sum(dims))
+    ref = ob.OracleLattice(*dims)
+    ref.init_mixture()
+    f0 = ref.f * (1.0 + 0.05 * rng.standard_normal(ref.f.shape))
+    g0 = ref.g * (1.0 + 0.05 * rng.standard_normal(ref.g.shape))
+    ref.init_from(f0, g0)
+    lbm = pkg.BinaryLBM(*dims, schedule=schedule)
+    lbm.LBM_init(f0.copy(), g0.copy())
+    _same(lbm.LBM_hydrovars(), ref.h, "hydrovs of uploaded state")
+    lbm.LBM_timestep(4)
+    for _ in range(4):
+        ref.timestep()
+    f, g = lbm.populations()
+    _same(f, ref.f, "f")
+    _same(g, ref.g, "g")
+    _same(lbm.LBM_hydrovars_density(), ref.hbar[:9], "hydrovsbar")
+    lbm.close()
+
+
 def test_survey_pins_on_gpu(pkg):
     """The three reference outputs recorded in SURVEY.md 8c (8^3 stripe, 10 steps)."""
     lbm = pkg.BinaryLBM(8, 8, 8)
