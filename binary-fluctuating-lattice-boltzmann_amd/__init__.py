@@ -8,6 +8,7 @@ from . import _lib
 from ._lib import BflbmError, Params, Domain, Fab, NVEL, NHYDRO, NHYDROBAR, HALO_STATE, HALO_NEXT, HALO_UPLOAD
 from .lattice import BinaryLBM, default_params, make_fab, rng_site_normals
 from .slab import SlabLattice, LocalSlabRing, slab_bounds
+from . import plotfile
 
 __all__ = ["SlabLattice", "LocalSlabRing", "slab_bounds", "BinaryLBM", "default_params", "make_fab", "rng_site_normals", "BflbmError",
            "Params", "Domain", "Fab", "NVEL", "NHYDRO", "NHYDROBAR"]

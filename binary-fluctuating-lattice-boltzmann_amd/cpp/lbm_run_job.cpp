@@ -4,7 +4,9 @@
 // project's host container.  It demonstrates that the operator surface is drop-in: the LBM_* calls
 // below are textually the reference's.
 //
-// usage: lbm_run_job <nx> [<ny> <nz>] <nsteps> <mixture|stripe|droplet> [kBT] [alpha0] [sync 0|1|2]
+// usage: lbm_run_job <nx> [<ny> <nz>] <nsteps> <mixture|stripe|droplet> [kBT] [alpha0] [sync 0|1|2] [plot_root]
+// With plot_root the final hydrovs frame, the noise and the f/g checkpoints are written as AMReX
+// plotfiles named like the reference's (main_run_job.cpp:42, :400-409; Debug.H:390-408).
 #include <algorithm>
 #include <array>
 #include <cctype>
@@ -17,6 +19,7 @@
 #include "host_multifab.H"
 using namespace bflbm::host;
 #include "../../include/bflbm_amrex.H"
+#include "../../include/bflbm_plotfile.H"
 
 int main(int argc, char* argv[]) {
   if (argc < 4) { std::fprintf(stderr, "usage: %s nx [ny nz] nsteps system [kBT] [alpha0] [sync]\n", argv[0]); return 2; }
@@ -30,6 +33,7 @@ int main(int argc, char* argv[]) {
   if (a < argc) kBT = std::atof(argv[a++]);
   if (a < argc) alpha0 = std::atof(argv[a++]);
   if (a < argc) bflbm::set_sync(std::atoi(argv[a++]));
+  const std::string plot_root = (a < argc) ? argv[a++] : "";
 
   const int max_grid_size = std::max(1, nx / 2);            // main_run_job.cpp:73
   Box domain(IntVect3{{0, 0, 0}}, IntVect3{{nx - 1, ny - 1, nz - 1}});
@@ -74,6 +78,16 @@ int main(int argc, char* argv[]) {
   // ghost cells must hold the periodic image after the adapter's FillBoundary
   MFIter it(hydrovsbar);
   std::printf("ghost_check %d\n", (int)(hydrovsbar[it](-1, 0, 0, 0) == hydrovsbar.at(nx - 1, 0, 0, 0)));
+  if (!plot_root.empty()) {
+    bool ok = bflbm::WriteSingleLevelPlotfile(bflbm::Concatenate(plot_root + "/plt", nsteps), hydrovs, bflbm::VariableNames(nhydro), geom, (double)nsteps, nsteps);
+    std::vector<std::string> nf, ng;
+    for (int k = 0; k < nvel; ++k) { nf.push_back("fa" + std::to_string(k)); ng.push_back("ga" + std::to_string(k)); }
+    ok = ok && bflbm::WriteSingleLevelPlotfile(bflbm::Concatenate(plot_root + "/fn", nsteps), fnoisevs, nf, geom, (double)nsteps, nsteps);
+    ok = ok && bflbm::WriteSingleLevelPlotfile(bflbm::Concatenate(plot_root + "/gn", nsteps), gnoisevs, ng, geom, (double)nsteps, nsteps);
+    ok = ok && bflbm::WriteSingleLevelPlotfile(bflbm::Concatenate(plot_root + "/f_checkpoint", nsteps), fold, {"rho_chk"}, geom, 0., 0);   // 1 name, 19 comps (:406-407)
+    ok = ok && bflbm::WriteSingleLevelPlotfile(bflbm::Concatenate(plot_root + "/g_checkpoint", nsteps), gold, {"phi_chk"}, geom, 0., 0);
+    std::printf("plotfiles %d\n", (int)ok);
+  }
   bflbm::shutdown();
   return 0;
 }

@@ -46,3 +46,30 @@ def test_sync_policies_give_identical_results():
     base = _run(10, 5, "droplet", 1e-5, 1.0, 2)
     for sync in (0, 1):
         assert _run(10, 5, "droplet", 1e-5, 1.0, sync) == base
+
+
+def test_cpp_driver_plotfiles_match_python_writer_and_oracle(pkg, ob, tmp_path):
+    """The driver writes hydrovs / noise / checkpoints as AMReX plotfiles (8 boxes of nx/2); the python
+    reader gets the oracle's fields back and the python writer reproduces the same bytes."""
+    import filecmp
+    pf = pkg.plotfile
+    n, steps = 8, 4
+    root = str(tmp_path / "data")
+    os.makedirs(root)
+    o = _run(n, steps, "droplet", 1e-5, 2.0, 2, root)
+    assert o["plotfiles"] == ["1"]
+    ref = ob.OracleLattice(n, n, n, params=ob.default_params(kBT=1e-5, alpha0=2.0))
+    ref.init_droplet(0.2)
+    for _ in range(steps):
+        ref.timestep()
+    h, hdr = pf.read_plotfile(pf.concatenate(root + "/plt", steps))
+    assert np.array_equal(h, ref.h) and hdr["names"] == pf.variable_names(22) and hdr["ngrids"] == 8
+    fn, _ = pf.read_plotfile(pf.concatenate(root + "/fn", steps))
+    assert np.array_equal(fn, ref.fn)
+    f, hdr = pf.read_plotfile(pf.concatenate(root + "/f_checkpoint", steps))
+    assert np.array_equal(f, ref.f) and hdr["names"] == ["rho_chk"] and hdr["ncomp"] == 19
+    # byte-identical twin
+    twin = pf.write_plotfile(str(tmp_path / "twin"), ref.h, pf.variable_names(22), time=float(steps), step=steps, max_grid_size=n // 2)
+    src = pf.concatenate(root + "/plt", steps)
+    for rel in ("Header", "Level_0/Cell_H", "Level_0/Cell_D_00000"):
+        assert filecmp.cmp(os.path.join(src, rel), os.path.join(twin, rel), shallow=False), rel
