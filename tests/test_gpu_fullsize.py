@@ -93,3 +93,25 @@ def test_upload_download_roundtrip_128(pkg):
         acc += f0[i]
     assert np.array_equal(hb[0], acc)              # sequential sum in index order (LBM_binary.H:322-328)
     lbm.close()
+
+
+def test_droplet_notebook_centre_of_mass_after_20000_steps(pkg):
+    """Droplet_Fluctuation.ipynb cell 5 (run of the reference itself, 2025-12-29): 64^3 droplet, header
+    defaults (alpha0=4, kBT=0, rho_hi=1, rho_lo=0, kappa=4, tau=1/2), r_init=0.2, frame 20000 ->
+    'Center of Mass: [0.50470332 0.50470332 0.50470332]' with cell-centred coordinates (i+0.5)/n weighted
+    by the 'rho' field.  An integrated observable of a 20000-step trajectory of the real reference; we
+    require all printed digits."""
+    n = 64
+    lbm = pkg.BinaryLBM(n, n, n)
+    lbm.LBM_init_droplet(0.2)
+    lbm.LBM_timestep(20000)
+    rho = lbm.LBM_hydrovars(ncomp=1)[0]
+    c = (np.arange(n) + 0.5) / n
+    m = rho.sum()
+    com = np.array([(rho * c[None, None, :]).sum(), (rho * c[None, :, None]).sum(), (rho * c[:, None, None]).sum()]) / m
+    assert ["%.8f" % v for v in com] == ["0.50470332"] * 3, com
+    # same number from the device-side reduction behind update_com (cell indices, LBM_hydrovs.H:46-48)
+    np.testing.assert_allclose((lbm.update_com() + 0.5) / n, com, rtol=1e-12)
+    r0, p0 = lbm.mass()
+    assert abs(r0 - 9313.703607) < 1e-5                      # rho mass is conserved from the initial profile
+    lbm.close()
