@@ -9,6 +9,7 @@ from ._lib import BflbmError, Params, Domain, Fab, NVEL, NHYDRO, NHYDROBAR, HALO
 from .lattice import BinaryLBM, default_params, make_fab, rng_site_normals
 from .slab import SlabLattice, LocalSlabRing, slab_bounds
 from . import plotfile
+from . import analysis
 
 __all__ = ["SlabLattice", "LocalSlabRing", "slab_bounds", "BinaryLBM", "default_params", "make_fab", "rng_site_normals", "BflbmError",
            "Params", "Domain", "Fab", "NVEL", "NHYDRO", "NHYDROBAR"]

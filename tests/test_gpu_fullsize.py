@@ -114,4 +114,15 @@ def test_droplet_notebook_centre_of_mass_after_20000_steps(pkg):
     np.testing.assert_allclose((lbm.update_com() + 0.5) / n, com, rtol=1e-12)
     r0, p0 = lbm.mass()
     assert abs(r0 - 9313.703607) < 1e-5                      # rho mass is conserved from the initial profile
+    # the other numbers of that notebook cell, with the notebook's definitions (analysis.py):
+    #   Fitted Droplet Radius: 0.1669310108163054
+    #   Eigenvalues: [0.03491747 0.03496081 0.03491747]   Principal Axes (a, b, c): [0.1668965  0.16700005 0.1668965 ]
+    an = pkg.analysis
+    rho_xyz = np.ascontiguousarray(rho.transpose(2, 1, 0))
+    assert ["%.8f" % v for v in an.centre_of_mass(rho_xyz)] == ["0.50470332"] * 3
+    hi, lo, R, W = an.fit_droplet(rho_xyz)
+    assert abs(R - 0.1669310108163054) < 2e-7, R             # least-squares optimum; scipy versions differ in the last digits
+    axes, ev, _ = an.principal_axes(rho_xyz, R)
+    assert np.allclose(np.sort(ev), np.sort([0.03491747, 0.03496081, 0.03491747]), rtol=0, atol=6e-9), ev
+    assert np.allclose(np.sort(axes), np.sort([0.1668965, 0.16700005, 0.1668965]), rtol=0, atol=3e-7), axes
     lbm.close()
