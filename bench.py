@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+METRIC = "MLUPS (million lattice-site updates/sec) D3Q19\u00d72 at 256\u00b3/512\u00b3; % HBM roofline"   # BASELINE.json
 BYTES_PER_LUP = 608.0          # 2 fluids x 19 populations x 8 B x (1 read + 1 write), BASELINE.md section 3
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -117,7 +118,7 @@ def main():
         achieved = per_gpu_sites * BYTES_PER_LUP / (kern_ms * 1e-3) / 1e9
         workload = f"{nx}x{ny}x{nz} periodic, {a.init} init, " + ("kBT=1e-5 alpha0=0" if a.noise else "zero noise")
         out = {
-            "metric": "MLUPS (million lattice-site updates/sec) D3Q19x2", "value": round(mlups, 1), "unit": "MLUPS",
+            "metric": METRIC, "value": round(mlups, 1), "unit": "MLUPS",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "schedule": a.schedule, "slab_per_gpu": f"{nx}x{ny}x{nz // world}",
