@@ -10,6 +10,7 @@ from .lattice import BinaryLBM, default_params, make_fab, rng_site_normals
 from .slab import SlabLattice, LocalSlabRing, slab_bounds
 from . import plotfile
 from . import analysis
+from . import structfact
 from . import run_job
 
 __all__ = ["SlabLattice", "LocalSlabRing", "slab_bounds", "BinaryLBM", "default_params", "make_fab", "rng_site_normals", "BflbmError",

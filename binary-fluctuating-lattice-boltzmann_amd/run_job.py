@@ -17,7 +17,8 @@ What it mirrors (main_run_job.cpp line numbers):
 Frames hold `hydrovs` (22 components, VariableNames) -- the reference's STRUCT_HYDROVARS variant; with
 --lb-hydrovars the 15-component `hydrovsbar` is written under the same names like the shipped
 STRUCT_LB_HYDROVARS build does (main_run_job.cpp:19, :321).
-Not mirrored: FHDeX structure factors (:301-310, :342-349; plot_SF_window = 0 in the shipped source).
+  * structure factors :99-103, :301-310, :342-349: accumulated every out_SF_step steps inside the last
+    plot_SF_window steps of a noisy run and written with the last frame (structfact.py; shipped window = 0)
 """
 import argparse
 import os
@@ -78,6 +79,8 @@ def main(argv=None):
     ap.add_argument("--plot-int", type=int, default=200)                   # :90
     ap.add_argument("--print-int", type=int, default=20)                   # :91
     ap.add_argument("--out-noise-step", type=int, default=0, help="0 = never (reference: nsteps+1)")   # :96
+    ap.add_argument("--plot-sf-window", type=int, default=0)               # :99
+    ap.add_argument("--out-sf-step", type=int, default=100)                # :100
     ap.add_argument("--step-continue", type=int, default=0)                # :80
     ap.add_argument("--continue-from-nonfluct", action="store_true", default=True)   # :84
     ap.add_argument("--restart", action="store_true", help="if_continue_from_last_frame (:248)")
@@ -151,11 +154,16 @@ def main(argv=None):
     print("LB initialized with alpha0 = %g and T = %g" % (a.alpha0, a.kbt))
 
     last = a.step_continue + a.nsteps
+    plot_sf = a.plot_sf_window if noise else 0                              # :102
+    sf = pkg.structfact.StructFact(names) if plot_sf > 0 else None          # :310
+    sf_start = last - a.plot_sf_window                                      # :330
     out_step = a.step_continue + 2 * a.nsteps // 10 if noise else a.step_continue    # :89
     for step in range(a.step_continue + 1, last + 1):                       # :335-387
         lbm.LBM_timestep(1)
         if a.print_int and step % a.print_int == 0 and step % (a.print_int * 50) == 0:
             print("LB step %d" % step)
+        if sf is not None and step >= sf_start and step % a.out_sf_step == 0:   # :342-349
+            sf.fort_structure(frame(), 0)
         if noise and a.out_noise_step and step % a.out_noise_step == 0:     # WriteOutNoise, Debug.H:380-409
             fn, gn = lbm.thermal_noise()
             base = paths["plot_root"][:-3]
@@ -165,6 +173,8 @@ def main(argv=None):
             write_output(step)
         if step == last:
             write_output(step)
+            if sf is not None and sf.nsamples:                              # WriteOutput(..., plot_SF) :50-54
+                sf.write_plotfile(step, float(step), paths["plot_root"] + "_SF", 1, mgs)
 
     f, g = lbm.populations()                                                # :400-409
     pf.write_plotfile(checkpoint_name(paths["chk_f"], last, a.alpha0, a.kbt, n), f, ["rho_chk"], 0.0, 0, mgs)

@@ -67,3 +67,25 @@ def test_noisy_job_writes_noise_frames(pkg, tmp_path):
     assert hdr["names"] == ["fa%d" % k for k in range(19)]          # NoiseCovariance.ipynb reads fa%d / ga%d
     assert np.all(fn[0] == 0) and np.array_equal(gn[1:4], -fn[1:4]) and fn[4:].std() > 0
     assert not os.path.exists(os.path.join(root, "data_mixture_hydrovars", "equilibrium_rho_alpha0_0.00_size8-8-8"))
+
+
+def test_noisy_job_structure_factor_window(pkg, tmp_path):
+    """main_run_job.cpp:99-103, :342-349: accumulate every out_SF_step inside the last plot_SF_window steps and
+    write <plot root>_SF_mag / _real_imag with the last frame; S_rho/(kBT/cs2) averages to ~1 (Mixture.ipynb)."""
+    pf = pkg.plotfile
+    root = str(tmp_path / "S")
+    kbt = 1e-5
+    assert pkg.run_job.main(["--system", "mixture", "--nx", "16", "--alpha0", "0", "--kbt", str(kbt), "--tau", "1",
+                             "--nsteps", "1500", "--plot-int", "500", "--plot-sf-window", "1000", "--out-sf-step", "20",
+                             "--print-int", "0", "--root", root]) == 0
+    run = os.path.join(root, "data_mixture_hydrovars", "lbm_data_shshan_alpha0_0.00_xi_1.0e-05_size16-16-16_continue")
+    mag, hdr = pf.read_plotfile(os.path.join(run, "plt_SF_mag000001500"))
+    assert hdr["names"][0] == "struct_fact_rho_rho" and mag.shape == (22, 16, 16, 16)
+    s_rho = mag[0] / (kbt * 3.0)
+    assert s_rho[8, 8, 8] == 0.0                                  # zero_avg: k = 0 sits at the box centre
+    assert abs(s_rho.sum() / (16 ** 3 - 1) - 1.0) < 0.05, s_rho.sum() / (16 ** 3 - 1)
+    # the lattice velocity ufbar = j_f/rho is the equipartitioned one (the real velocity ufx mixes in the
+    # inter-species relaxation and half the momentum noise, cf. the markdown cell 1 of Mixture.ipynb)
+    k = hdr["names"].index("struct_fact_ufbarx_ufbarx")
+    assert abs(mag[k].sum() / (16 ** 3 - 1) / kbt - 1.0) < 0.08, mag[k].sum() / (16 ** 3 - 1) / kbt
+    assert os.path.isdir(os.path.join(run, "plt_SF_real_imag000001500"))

@@ -64,3 +64,36 @@ def test_checkpoint_quirk_one_name_many_components(pkg, tmp_path):
     back, hdr = pf.read_plotfile(name)
     assert hdr["names"] == ["rho_chk"] and hdr["ncomp"] == 19
     assert np.array_equal(back, f)
+
+
+def test_structfact_accumulator(pkg, tmp_path):
+    """StructFact re-statement: pair naming and layout as read by Mixture.ipynb cell 2, normalisation
+    S = a^ conj(b^)/N (Parseval: mean over k of S_aa = <a^2>), k = 0 at the box centre and removed."""
+    sfm, pf = pkg.structfact, pkg.plotfile
+    rng = np.random.default_rng(3)
+    names = pf.variable_names(22)
+    sf = sfm.StructFact(names)
+    assert sf.pair_names()[0] == "struct_fact_rho_rho" and "struct_fact_ugx_ufx" in sf.pair_names() \
+        and "struct_fact_phi_rho" in sf.pair_names() and len(sf.pair_names()) == 22
+    n = 8
+    frames = [rng.standard_normal((22, n, n, n)) for _ in range(5)]
+    for fr in frames:
+        sf.fort_structure(fr)
+    s = sf.write_plotfile(600500, 600500.0, str(tmp_path / "plt_SF"), zero_avg=1, max_grid_size=4)
+    mag, hdr = pf.read_plotfile(str(tmp_path / "plt_SF_mag000600500"))          # 9-digit step like the notebook path
+    assert hdr["names"] == sf.pair_names() and np.array_equal(mag, np.abs(s))
+    ri, hdr = pf.read_plotfile(str(tmp_path / "plt_SF_real_imag000600500"))
+    assert hdr["names"][0] == "struct_fact_rho_rho_real" and hdr["names"][22] == "struct_fact_rho_rho_imag"
+    assert np.array_equal(ri[:22], s.real) and np.array_equal(ri[22:], s.imag)
+    assert np.all(mag[:, n // 2, n // 2, n // 2] == 0)                           # zero_avg
+    head = open(str(tmp_path / "plt_SF_mag000600500" / "Header")).read().split("\n")
+    assert head[2 + 22 + 3].split() == ["-4.5", "-4.5", "-4.5"] and head[2 + 22 + 4].split() == ["3.5", "3.5", "3.5"]
+    # Parseval on the rho-rho pair (without removing k = 0)
+    full = sf.mean(zero_avg=0)[0]
+    want = np.mean([(fr[0] ** 2).mean() for fr in frames])
+    assert abs(full.real.mean() - want) < 1e-12
+    # cross pair ugx-ufx is the conjugate-symmetric product a^ conj(b^): A = ufx (2), B = ugx (6)
+    k = sf.pair_names().index("struct_fact_ugx_ufx")
+    a, b = np.fft.fftn(frames[0][2]), np.fft.fftn(frames[0][6])
+    one = sfm.StructFact(names); one.fort_structure(frames[0])
+    assert np.allclose(np.fft.ifftshift(one.mean(0)[k]), a * np.conj(b) / n ** 3)
