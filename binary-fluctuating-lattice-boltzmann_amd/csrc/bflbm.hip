@@ -81,7 +81,6 @@ struct bflbm_ctx {
   Geo G;
   int nzl = 0;
   double* S[2] = {nullptr, nullptr};
-  double* S_alloc[2] = {nullptr, nullptr};
   int cur = 0;
   double* rho = nullptr;
   double* phi = nullptr;
@@ -274,13 +273,7 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   const size_t sbytes = (size_t)2 * Q * G.vol * sizeof(double);
   const size_t fbytes = (size_t)G.vol * sizeof(double);
   hipError_t e = hipSuccess;
-  // the B buffer is additionally shifted against the A buffer (BFLBM_PAD_AB doubles, tuning override)
-  static const long long pad_ab = [] { const char* e2 = getenv("BFLBM_PAD_AB"); return e2 ? atoll(e2) : 0LL; }();
-  c->S_alloc[0] = c->S_alloc[1] = nullptr;
-  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-    e = hipMalloc((void**)&c->S_alloc[k], sbytes + (size_t)pad_ab * sizeof(double));
-    c->S[k] = c->S_alloc[k] ? c->S_alloc[k] + (k == 1 ? pad_ab : 0) : nullptr;
-  }
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipMalloc((void**)&c->S[k], sbytes);
   if (e == hipSuccess) e = hipMalloc((void**)&c->rho, fbytes);
   if (e == hipSuccess) e = hipMalloc((void**)&c->phi, fbytes);
   c->partial_n = (size_t)((G.plane + 255) / 256) * (size_t)c->nzl;
@@ -308,7 +301,7 @@ int bflbm_destroy(bflbm_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->dom.device);
   if (c->stream && c->own_stream) hipStreamSynchronize(c->stream);
-  for (int k = 0; k < 2; ++k) if (c->S_alloc[k]) hipFree(c->S_alloc[k]);
+  for (int k = 0; k < 2; ++k) if (c->S[k]) hipFree(c->S[k]);
   if (c->rho) hipFree(c->rho);
   if (c->phi) hipFree(c->phi);
   if (c->injf) hipFree(c->injf);

@@ -55,14 +55,6 @@ __device__ __forceinline__ bool fused_map(const FusedGrid& F, int b, int& col, i
 #else
 #define STAMP(k) do {} while (0)
 #endif
-#ifndef BFLBM_NT_STORE
-#define BFLBM_NT_STORE 0
-#endif
-#if BFLBM_NT_STORE
-#define BFLBM_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define BFLBM_STORE(p, v) (*(p) = (v))
-#endif
 #ifndef BFLBM_ABL
 #define BFLBM_ABL 0   // ablation switches for timing experiments only (results become wrong)
 #endif
@@ -253,7 +245,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
           double out[Q];
           d_populations(mf, out);
 #pragma unroll
-          for (int i = 0; i < Q; ++i) BFLBM_STORE(&Dp[(long long)i * G.vol + o], out[i]);
+          for (int i = 0; i < Q; ++i) Dp[(long long)i * G.vol + o] = out[i];
         }
         {
           double gn[Q];
@@ -270,7 +262,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
           double out[Q];
           d_populations(mg, out);
 #pragma unroll
-          for (int i = 0; i < Q; ++i) BFLBM_STORE(&Dp[(long long)(i + Q) * G.vol + o], out[i]);
+          for (int i = 0; i < Q; ++i) Dp[(long long)(i + Q) * G.vol + o] = out[i];
         }
       }
     }

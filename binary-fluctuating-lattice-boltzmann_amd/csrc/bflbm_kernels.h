@@ -22,10 +22,6 @@ struct Geo {
   long long vol;       // nzs*plane = component stride
 };
 
-__device__ __constant__ const int kCX[Q] = BFLBM_CX;
-__device__ __constant__ const int kCY[Q] = BFLBM_CY;
-__device__ __constant__ const int kCZ[Q] = BFLBM_CZ;
-
 // compile-time velocity tables for fully unrolled loops
 struct Vel {
   static constexpr int cx[Q] = BFLBM_CX;
