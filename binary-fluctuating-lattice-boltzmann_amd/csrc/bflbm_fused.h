@@ -304,11 +304,15 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   // enough chunks to fill the chip a few times over (2 workgroups resident per CU), chunks of
   // >= 16 planes; BFLBM_FUSED_WG overrides the target workgroup count (tuning only)
   static const int want_env = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 0; }();
-  // Single slab: 512 workgroups (two rounds of one 512-thread workgroup per CU).  Slab of a
-  // multi-GPU run: 1024 shorter ones, so that the RCCL copy kernels of the overlapped exchange,
-  // which need a few CUs of their own, delay at most a short tail of the interior sweep.
-  const int want = want_env > 0 ? want_env : (G.zwrap ? 512 : 1024);
-  int nchunks = (want + F.ncols - 1) / F.ncols;
+  // Single slab: at least one workgroup per CU (256) and marches of at most 256 planes (longer ones
+  // let neighbouring workgroups drift apart and lose L2 sharing: 256^3 -> 2 chunks x 128 columns,
+  // 512^3 -> 2 chunks x 512 columns; measured best on MI355X).  Slab of a multi-GPU run: ~1024
+  // shorter workgroups, so that the RCCL copy kernels of the overlapped exchange, which need a few
+  // CUs of their own, delay at most a short tail of the interior sweep.
+  int nchunks;
+  if (want_env > 0)   nchunks = (want_env + F.ncols - 1) / F.ncols;
+  else if (G.zwrap)   nchunks = std::max((256 + F.ncols - 1) / F.ncols, (np + 255) / 256);
+  else                nchunks = (1024 + F.ncols - 1) / F.ncols;
   const int maxchunks = (np + 15) / 16;
   if (nchunks > maxchunks) nchunks = maxchunks;
   if (nchunks < 1) nchunks = 1;
