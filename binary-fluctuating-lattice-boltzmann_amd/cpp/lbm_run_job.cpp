@@ -41,7 +41,10 @@ int main(int argc, char* argv[]) {
   BoxArray ba(domain);
   ba.maxSize(max_grid_size);                                // :142
   const int nghost = 2;                                     // :145
-  const int nhydro = 22;                                    // :147
+  // LBM_LEGACY=1: the stale drivers' settings -- nhydro = 15 (main_driver.cpp:165) and the 12-argument
+  // LBM_timestep without com_ref (main_driver.cpp:336); the adapter must never write past nComp().
+  const bool legacy = std::getenv("LBM_LEGACY") && std::atoi(std::getenv("LBM_LEGACY")) != 0;
+  const int nhydro = legacy ? 15 : 22;                      // :147
 
   MultiFab rho_eq(ba, 1, nghost, domain), phi_eq(ba, 1, nghost, domain), rhot_eq(ba, 1, nghost, domain);
   rhot_eq.setVal(1.);
@@ -59,7 +62,14 @@ int main(int argc, char* argv[]) {
   std::printf("LB initialized with alpha0 = %g and T = %g, %zu boxes of max size %d\n", (double)alpha0, (double)kBT, ba.size(), max_grid_size);
 
   for (int step = 1; step <= nsteps; ++step) {              // :335-339
-    LBM_timestep(geom, fold, gold, fnew, gnew, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq, com_ref);
+    if (legacy) LBM_timestep(geom, fold, gold, fnew, gnew, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq);
+    else        LBM_timestep(geom, fold, gold, fnew, gnew, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq, com_ref);
+  }
+  // restart path of the live driver (:253-270): continue from the populations just produced
+  if (std::getenv("LBM_RESTART_CHECK") && std::atoi(std::getenv("LBM_RESTART_CHECK")) != 0) {
+    MultiFab f_last(ba, nvel, nghost, domain), g_last(ba, nvel, nghost, domain);
+    bflbm::pull_field(geom, bflbm::F_POPS, f_last, &g_last);
+    LBM_init(geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs, f_last, g_last, rho_eq, phi_eq, rhot_eq, com_ref);
   }
   bflbm::materialize(geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs);   // no-op cost when sync == 2
 

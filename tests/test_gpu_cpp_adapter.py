@@ -73,3 +73,24 @@ def test_cpp_driver_plotfiles_match_python_writer_and_oracle(pkg, ob, tmp_path):
     src = pf.concatenate(root + "/plt", steps)
     for rel in ("Header", "Level_0/Cell_H", "Level_0/Cell_D_00000"):
         assert filecmp.cmp(os.path.join(src, rel), os.path.join(twin, rel), shallow=False), rel
+
+
+def _run_env(env, *args):
+    e = dict(os.environ, **env)
+    r = subprocess.run([EXE, *map(str, args)], capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0, r.stderr
+    return {ln.partition(" ")[0]: ln.partition(" ")[2].split() for ln in r.stdout.splitlines()}
+
+
+def test_legacy_arity_and_15_component_hydrovs():
+    """the stale drivers call LBM_timestep with 12 arguments and allocate nhydro = 15."""
+    new = _run(8, 10, "stripe")
+    old = _run_env({"LBM_LEGACY": "1"}, 8, 10, "stripe")
+    for key in ("rho(0,0,4)", "ufz(0,0,2)", "rho_mass", "fold(1,1,1,3)", "com"):
+        assert old[key] == new[key], key
+    assert float(old["rho(0,0,4)"][0]) == float("1.0185845986909126")
+
+
+def test_restart_through_cpp_lbm_init_is_transparent():
+    """LBM_init(geom, ..., mf0, mg0, ..., com_ref) with the populations just downloaded leaves every output unchanged."""
+    assert _run_env({"LBM_RESTART_CHECK": "1"}, 10, 6, "droplet", 0, 2.0) == _run(10, 6, "droplet", 0, 2.0)
