@@ -166,32 +166,36 @@ class SlabLattice(_Protocol):
 
 
 class LocalSlabRing:
-    """Several slabs of one lattice held by ONE process (all on one GPU): the same protocol with
-    device-to-device copies instead of RCCL.  Used to validate the slab path on a 1-GPU box and
-    to run lattices larger than one allocation."""
+    """Several slabs of one lattice driven by ONE process -- the way the reference itself runs
+    (single process, USE_MPI=FALSE).  `devices` places slab r on GPU devices[r % len(devices)]: one
+    GPU (validation on a 1-GPU box, lattices larger than one allocation) or all GPUs of the node,
+    with the halo buffers moved by device-to-device (peer, xGMI) copies instead of RCCL."""
 
-    def __init__(self, nx, ny, nz, nslabs, params=None, device=0, schedule=None, engine_factory=None):
+    def __init__(self, nx, ny, nz, nslabs, params=None, device=0, schedule=None, engine_factory=None, devices=None):
         self.n = (nx, ny, nz)
         self.nslabs = int(nslabs)
+        self.devices = list(devices) if devices is not None else [device]
         self.engines = []
         for r in range(self.nslabs):
             z0, z1 = slab_bounds(nz, self.nslabs, r)
             if engine_factory is None:
                 e = BinaryLBM(nx, ny, nz, params=params, z0=z0, z1=z1, rank=r, nranks=self.nslabs,
-                              device=device, schedule=schedule)
+                              device=self.devices[r % len(self.devices)], schedule=schedule)
             else:
                 e = engine_factory(nx, ny, nz, z0, z1, r, self.nslabs)
             self.engines.append(e)
-        self._alloc = None
         self._bufs = None
 
     def _buffers(self):
+        """Per slab: send_lo, send_hi, recv_lo, recv_hi on that slab's device."""
         if self._bufs is None:
             import torch
             e0 = self.engines[0]
             n = e0.halo_bytes(_lib.HALO_STATE) // 8
-            dev = "cuda" if isinstance(e0, BinaryLBM) else "cpu"
-            self._bufs = [[torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)] for _ in self.engines]
+            self._bufs = []
+            for r, e in enumerate(self.engines):
+                dev = ("cuda:%d" % self.devices[r % len(self.devices)]) if isinstance(e, BinaryLBM) else "cpu"
+                self._bufs.append([torch.empty(n, dtype=torch.float64, device=dev) for _ in range(4)])
         return self._bufs
 
     def _sync_all(self):
@@ -201,15 +205,22 @@ class LocalSlabRing:
     def exchange(self, kind):
         if self.nslabs == 1:
             return
+        import torch
         bufs = self._buffers()
         for r, e in enumerate(self.engines):
             e.halo_pack(kind, 0, bufs[r][0].data_ptr())
             e.halo_pack(kind, 1, bufs[r][1].data_ptr())
         self._sync_all()                       # contexts use independent streams
-        for r, e in enumerate(self.engines):
+        for r in range(self.nslabs):
             lower, upper = (r - 1) % self.nslabs, (r + 1) % self.nslabs
-            e.halo_unpack(kind, 0, bufs[lower][1].data_ptr())   # lower neighbour's high face
-            e.halo_unpack(kind, 1, bufs[upper][0].data_ptr())   # upper neighbour's low face
+            bufs[r][2].copy_(bufs[lower][1])   # recv_lo <- lower neighbour's high face (peer copy across GPUs)
+            bufs[r][3].copy_(bufs[upper][0])   # recv_hi <- upper neighbour's low face
+        if bufs[0][0].is_cuda:
+            for d in set(self.devices):
+                torch.cuda.synchronize(d)
+        for r, e in enumerate(self.engines):
+            e.halo_unpack(kind, 0, bufs[r][2].data_ptr())
+            e.halo_unpack(kind, 1, bufs[r][3].data_ptr())
         self._sync_all()
 
     def LBM_timestep(self, nsteps=1):
