@@ -105,7 +105,7 @@ class BinaryLBM:
         check(self.lib.bflbm_set_params(self._h, ctypes.byref(self.params)))
 
     def set_schedule(self, schedule):
-        code = {"two_pass": 0, "fused": 1}.get(schedule, schedule)
+        code = {"two_pass": 0, "fused": 1, "auto": 2}.get(schedule, schedule)
         check(self.lib.bflbm_set_schedule(self._h, int(code)))
 
     # -- shapes ----------------------------------------------------------------------------

@@ -91,7 +91,8 @@ int bflbm_get_params(const bflbm_ctx* c, bflbm_params* p);
  * external == 0: go back to the context's own non-blocking stream (hip_stream ignored). */
 int bflbm_set_stream(bflbm_ctx* c, void* hip_stream, int external);
 
-/* Kernel schedule: 0 = two-pass (density pass + collide pass), 1 = fused plane-marching kernel. */
+/* Kernel schedule: 0 = two-pass (density pass + collide pass), 1 = fused plane-marching kernel,
+ * 2 = auto (default): fused at zero noise, two-pass when thermal noise is on. Results are identical. */
 int bflbm_set_schedule(bflbm_ctx* c, int schedule);
 
 /* LBM_init_mixture (LBM_binary.H:598-629), LBM_init_stripe(frac) (:664-695),

@@ -57,6 +57,7 @@ def test_error_conventions(pkg):
         lbm.LBM_hydrovars_density(out, fab)
     with pytest.raises(pkg.BflbmError):
         lbm.set_schedule(7)
+    lbm.set_schedule("auto")
     with pytest.raises(TypeError):
         lbm.upload(np.zeros((19, 8, 8, 8), dtype=np.float32), np.zeros((19, 8, 8, 8)))
     assert lbm.steps_done == 1
