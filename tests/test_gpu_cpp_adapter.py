@@ -11,6 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "binary-fluctuating-lattice-boltzmann_amd", "cpp", "lbm_run_job")
 
 
+@pytest.fixture(autouse=True)
+def _built(pkg):        # the pkg fixture builds csrc/ and cpp/ when needed
+    assert os.path.exists(EXE)
+
+
 def _run(*args):
     r = subprocess.run([EXE, *map(str, args)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
