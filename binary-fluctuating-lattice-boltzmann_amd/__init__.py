@@ -6,12 +6,12 @@ The product path needs the HIP library csrc/libbflbm.so; there is no CPU fallbac
 """
 from . import _lib
 from ._lib import BflbmError, Params, Domain, Fab, NVEL, NHYDRO, NHYDROBAR, HALO_STATE, HALO_NEXT, HALO_UPLOAD
-from .lattice import BinaryLBM, default_params, make_fab, rng_site_normals
+from .lattice import BinaryLBM, RingLBM, default_params, make_fab, rng_site_normals
 from .slab import SlabLattice, LocalSlabRing, slab_bounds
 from . import plotfile
 from . import analysis
 from . import structfact
 from . import run_job
 
-__all__ = ["SlabLattice", "LocalSlabRing", "slab_bounds", "BinaryLBM", "default_params", "make_fab", "rng_site_normals", "BflbmError",
+__all__ = ["RingLBM", "SlabLattice", "LocalSlabRing", "slab_bounds", "BinaryLBM", "default_params", "make_fab", "rng_site_normals", "BflbmError",
            "Params", "Domain", "Fab", "NVEL", "NHYDRO", "NHYDROBAR"]

@@ -68,6 +68,20 @@ SIGNATURES = {
     "bflbm_halo_bytes": (ctypes.c_int, [_vp, ctypes.c_int, _P(ctypes.c_size_t)]),
     "bflbm_halo_pack": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     "bflbm_halo_unpack": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "bflbm_ring_create": (ctypes.c_int, [_P(Params), _P(ctypes.c_int), ctypes.c_int, _P(ctypes.c_int), ctypes.c_int, _P(_vp)]),
+    "bflbm_ring_destroy": (ctypes.c_int, [_vp]),
+    "bflbm_ring_size": (ctypes.c_int, [_vp, _P(ctypes.c_int)]),
+    "bflbm_ring_slab": (ctypes.c_int, [_vp, ctypes.c_int, _P(_vp)]),
+    "bflbm_ring_set_params": (ctypes.c_int, [_vp, _P(Params)]),
+    "bflbm_ring_set_schedule": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "bflbm_ring_init_mixture": (ctypes.c_int, [_vp]),
+    "bflbm_ring_init_stripe": (ctypes.c_int, [_vp, ctypes.c_double]),
+    "bflbm_ring_init_droplet": (ctypes.c_int, [_vp, ctypes.c_double]),
+    "bflbm_ring_commit_upload": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "bflbm_ring_step": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "bflbm_ring_com_sums": (ctypes.c_int, [_vp, _dp]),
+    "bflbm_ring_mass": (ctypes.c_int, [_vp, _dp, _dp]),
+    "bflbm_ring_sync": (ctypes.c_int, [_vp]),
     "bflbm_get_hydrovsbar": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _P(Fab)]),
     "bflbm_get_hydrovs": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _P(Fab)]),
     "bflbm_get_noise": (ctypes.c_int, [_vp, _vp, _vp, _P(Fab)]),

@@ -702,4 +702,202 @@ int bflbm_device_bytes(const bflbm_ctx* c, size_t* bytes) {
   return 0;
 }
 
+
+// ---- single-process ring of slabs -----------------------------------------------------------
+struct bflbm_ring {
+  std::vector<bflbm_ctx*> ctx;
+  std::vector<hipStream_t> comm;        // per slab: copies + unpack, concurrent with the interior kernel
+  std::vector<hipEvent_t> packed;       // per slab: both faces packed (recorded on the slab's main stream)
+  std::vector<hipEvent_t> unpacked;     // per slab: both halo faces stored (recorded on the comm stream)
+  std::vector<double*> send[2], recv[2];
+  size_t bytes = 0;
+};
+
+static int ring_exchange(bflbm_ring* r, int kind) {
+  const int n = (int)r->ctx.size();
+  if (n == 1) return 0;
+  for (int k = 0; k < n; ++k) {
+    bflbm_ctx* c = r->ctx[k];
+    if (bflbm_halo_pack(c, kind, 0, r->send[0][k])) return 1;
+    if (bflbm_halo_pack(c, kind, 1, r->send[1][k])) return 1;
+    HIP_TRY(hipEventRecord(r->packed[k], c->stream));
+  }
+  for (int k = 0; k < n; ++k) {
+    bflbm_ctx* c = r->ctx[k];
+    const int lower = (k + n - 1) % n, upper = (k + 1) % n;
+    HIP_TRY(hipSetDevice(c->dom.device));
+    HIP_TRY(hipStreamWaitEvent(r->comm[k], r->packed[lower], 0));
+    HIP_TRY(hipStreamWaitEvent(r->comm[k], r->packed[upper], 0));
+    HIP_TRY(hipStreamWaitEvent(r->comm[k], r->packed[k], 0));     // my own halo planes must not be overwritten earlier
+    // my low halo <- lower neighbour's high face; my high halo <- upper neighbour's low face
+    HIP_TRY(hipMemcpyPeerAsync(r->recv[0][k], c->dom.device, r->send[1][lower], r->ctx[lower]->dom.device, r->bytes, r->comm[k]));
+    HIP_TRY(hipMemcpyPeerAsync(r->recv[1][k], c->dom.device, r->send[0][upper], r->ctx[upper]->dom.device, r->bytes, r->comm[k]));
+    for (int side = 0; side < 2; ++side) {
+      HaloTable T; halo_table(c, kind, side, false, T);
+      hipLaunchKernelGGL(k_halo_unpack, plane_grid(c, 2 * Q), dim3(256), 0, r->comm[k], halo_buffer(c, kind),
+                         (const double*)r->recv[side][k], c->G, T);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(r->unpacked[k], r->comm[k]));
+    if (kind == BFLBM_HALO_STATE) c->density_valid = false;
+  }
+  return 0;
+}
+
+// everything later on a slab's main stream sees the stored halos
+static int ring_join(bflbm_ring* r) {
+  const int n = (int)r->ctx.size();
+  if (n == 1) return 0;
+  for (int k = 0; k < n; ++k) {
+    HIP_TRY(hipSetDevice(r->ctx[k]->dom.device));
+    HIP_TRY(hipStreamWaitEvent(r->ctx[k]->stream, r->unpacked[k], 0));
+    // a neighbour must not re-pack (overwrite its send buffers) before my copies of them are done
+    HIP_TRY(hipStreamWaitEvent(r->ctx[k]->stream, r->unpacked[(k + 1) % n], 0));
+    HIP_TRY(hipStreamWaitEvent(r->ctx[k]->stream, r->unpacked[(k + n - 1) % n], 0));
+  }
+  return 0;
+}
+
+int bflbm_ring_create(const bflbm_params* p, const int n[3], int nslabs, const int* devices, int ndevices, bflbm_ring** out) {
+  if (!p || !n || !out || nslabs < 1) return fail("bflbm_ring_create: bad argument");
+  if (nslabs > 1 && n[2] / nslabs < 4) return fail("bflbm_ring_create: every slab needs at least 4 planes");
+  bflbm_ring* r = new bflbm_ring();
+  for (int k = 0; k < nslabs; ++k) {
+    bflbm_domain d;
+    for (int a = 0; a < 3; ++a) d.n[a] = n[a];
+    d.z0 = (int)((long long)n[2] * k / nslabs); d.z1 = (int)((long long)n[2] * (k + 1) / nslabs);
+    d.rank = k; d.nranks = nslabs;
+    d.device = (devices && ndevices > 0) ? devices[k % ndevices] : 0;
+    bflbm_ctx* c = nullptr;
+    if (bflbm_create(p, &d, &c)) { bflbm_ring_destroy(r); return 1; }
+    r->ctx.push_back(c);
+  }
+  if (nslabs > 1) {
+    size_t b = 0;
+    bflbm_halo_bytes(r->ctx[0], BFLBM_HALO_STATE, &b);
+    r->bytes = b;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < nslabs && e == hipSuccess; ++k) {
+      e = hipSetDevice(r->ctx[k]->dom.device);
+      hipStream_t st = nullptr; hipEvent_t e1 = nullptr, e2 = nullptr;
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&e2, hipEventDisableTiming);
+      r->comm.push_back(st); r->packed.push_back(e1); r->unpacked.push_back(e2);
+      for (int side = 0; side < 2; ++side) {
+        double *s1 = nullptr, *r1 = nullptr;
+        if (e == hipSuccess) e = hipMalloc((void**)&s1, b);
+        if (e == hipSuccess) e = hipMalloc((void**)&r1, b);
+        r->send[side].push_back(s1); r->recv[side].push_back(r1);
+      }
+      // peer access to the ring neighbours' send buffers (a no-op when they share the device)
+      for (int nb : { (k + 1) % nslabs, (k + nslabs - 1) % nslabs }) {
+        const int pd = r->ctx[nb]->dom.device;
+        if (pd != r->ctx[k]->dom.device) { int can = 0; hipDeviceCanAccessPeer(&can, r->ctx[k]->dom.device, pd); if (can) hipDeviceEnablePeerAccess(pd, 0); (void)hipGetLastError(); }
+      }
+    }
+    if (e != hipSuccess) { fail("bflbm_ring_create: %s", hipGetErrorString(e)); bflbm_ring_destroy(r); return 1; }
+  }
+  *out = r;
+  return 0;
+}
+
+int bflbm_ring_destroy(bflbm_ring* r) {
+  if (!r) return 0;
+  for (size_t k = 0; k < r->ctx.size(); ++k) {
+    hipSetDevice(r->ctx[k]->dom.device);
+    if (k < r->comm.size() && r->comm[k]) { hipStreamSynchronize(r->comm[k]); hipStreamDestroy(r->comm[k]); }
+    if (k < r->packed.size() && r->packed[k]) hipEventDestroy(r->packed[k]);
+    if (k < r->unpacked.size() && r->unpacked[k]) hipEventDestroy(r->unpacked[k]);
+    for (int side = 0; side < 2; ++side) {
+      if (k < r->send[side].size() && r->send[side][k]) hipFree(r->send[side][k]);
+      if (k < r->recv[side].size() && r->recv[side][k]) hipFree(r->recv[side][k]);
+    }
+    bflbm_destroy(r->ctx[k]);
+  }
+  delete r;
+  return 0;
+}
+
+int bflbm_ring_size(const bflbm_ring* r, int* nslabs) {
+  if (!r || !nslabs) return fail("null argument");
+  *nslabs = (int)r->ctx.size();
+  return 0;
+}
+
+int bflbm_ring_slab(bflbm_ring* r, int slab, bflbm_ctx** ctx) {
+  if (!r || !ctx || slab < 0 || slab >= (int)r->ctx.size()) return fail("bflbm_ring_slab: bad argument");
+  *ctx = r->ctx[slab];
+  return 0;
+}
+
+int bflbm_ring_set_params(bflbm_ring* r, const bflbm_params* p) {
+  if (!r) return fail("null ring");
+  for (bflbm_ctx* c : r->ctx) if (bflbm_set_params(c, p)) return 1;
+  return 0;
+}
+int bflbm_ring_set_schedule(bflbm_ring* r, int schedule) {
+  if (!r) return fail("null ring");
+  for (bflbm_ctx* c : r->ctx) if (bflbm_set_schedule(c, schedule)) return 1;
+  return 0;
+}
+int bflbm_ring_init_mixture(bflbm_ring* r) {
+  if (!r) return fail("null ring");
+  for (bflbm_ctx* c : r->ctx) if (bflbm_init_mixture(c)) return 1;
+  return 0;
+}
+int bflbm_ring_init_stripe(bflbm_ring* r, double frac) {
+  if (!r) return fail("null ring");
+  for (bflbm_ctx* c : r->ctx) if (bflbm_init_stripe(c, frac)) return 1;
+  return 0;
+}
+int bflbm_ring_init_droplet(bflbm_ring* r, double radius) {
+  if (!r) return fail("null ring");
+  for (bflbm_ctx* c : r->ctx) if (bflbm_init_droplet(c, radius)) return 1;
+  return 0;
+}
+
+int bflbm_ring_commit_upload(bflbm_ring* r, int reset) {
+  if (!r) return fail("null ring");
+  if (ring_exchange(r, BFLBM_HALO_UPLOAD) || ring_join(r)) return 1;
+  for (bflbm_ctx* c : r->ctx) if (bflbm_commit_upload(c, reset)) return 1;
+  if (ring_exchange(r, BFLBM_HALO_STATE) || ring_join(r)) return 1;
+  return bflbm_ring_sync(r);
+}
+
+int bflbm_ring_step(bflbm_ring* r, int nsteps) {
+  if (!r) return fail("null ring");
+  if (nsteps < 0) return fail("nsteps < 0");
+  if (r->ctx.size() == 1) return bflbm_step(r->ctx[0], nsteps);
+  for (int s = 0; s < nsteps; ++s) {
+    for (bflbm_ctx* c : r->ctx) if (bflbm_step_boundary(c)) return 1;
+    if (ring_exchange(r, BFLBM_HALO_NEXT)) return 1;       // comm streams: copies + unpack ...
+    for (bflbm_ctx* c : r->ctx) if (bflbm_step_interior(c)) return 1;   // ... while the main streams sweep the interior
+    if (ring_join(r)) return 1;
+    for (bflbm_ctx* c : r->ctx) if (bflbm_step_finish(c)) return 1;
+  }
+  return 0;
+}
+
+int bflbm_ring_com_sums(bflbm_ring* r, double sums[4]) {
+  if (!r || !sums) return fail("null argument");
+  for (int k = 0; k < 4; ++k) sums[k] = 0.;
+  for (bflbm_ctx* c : r->ctx) { double s[4]; if (bflbm_com_sums(c, s)) return 1; for (int k = 0; k < 4; ++k) sums[k] += s[k]; }
+  return 0;
+}
+int bflbm_ring_mass(bflbm_ring* r, double* rho_sum, double* phi_sum) {
+  if (!r || !rho_sum || !phi_sum) return fail("null argument");
+  *rho_sum = 0.; *phi_sum = 0.;
+  for (bflbm_ctx* c : r->ctx) { double a, b; if (bflbm_mass(c, &a, &b)) return 1; *rho_sum += a; *phi_sum += b; }
+  return 0;
+}
+int bflbm_ring_sync(bflbm_ring* r) {
+  if (!r) return fail("null ring");
+  for (size_t k = 0; k < r->ctx.size(); ++k) {
+    if (bflbm_sync(r->ctx[k])) return 1;
+    if (k < r->comm.size()) HIP_TRY(hipStreamSynchronize(r->comm[k]));
+  }
+  return 0;
+}
+
 }  // extern "C"

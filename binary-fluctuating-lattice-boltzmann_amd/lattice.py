@@ -78,10 +78,21 @@ class BinaryLBM:
         if schedule is not None:
             self.set_schedule(schedule)
 
+    @classmethod
+    def _borrow(cls, handle, n, z0, z1, rank, nranks, params):
+        """View on a context owned by someone else (a slab of a RingLBM); close() does not destroy it."""
+        self = cls.__new__(cls)
+        self.lib = _lib.load()
+        self.n, self.z0, self.z1, self.nzl = tuple(n), int(z0), int(z1), int(z1) - int(z0)
+        self.rank, self.nranks, self.params = int(rank), int(nranks), params
+        self._h, self._borrowed = handle, True
+        return self
+
     # -- lifetime -------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
-            self.lib.bflbm_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.bflbm_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -263,6 +274,119 @@ class BinaryLBM:
         n = ctypes.c_size_t()
         check(self.lib.bflbm_device_bytes(self._h, ctypes.byref(n)))
         return n.value
+
+
+class RingLBM:
+    """The whole lattice as a ring of z-slabs driven by this one process through the native ring of the
+    C-ABI (bflbm_ring_*): slab r on GPU devices[r % len(devices)], halo exchange by peer copies overlapped
+    with the interior planes.  Same operator surface as BinaryLBM; fields are full-lattice arrays."""
+
+    def __init__(self, nx, ny=None, nz=None, nslabs=1, devices=(0,), params=None, schedule=None):
+        self.lib = _lib.load()
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        self.n = (int(nx), int(ny), int(nz))
+        self.params = params if params is not None else default_params()
+        n3 = (ctypes.c_int * 3)(*self.n)
+        dev = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        h = ctypes.c_void_p()
+        check(self.lib.bflbm_ring_create(ctypes.byref(self.params), n3, int(nslabs), dev, len(devices), ctypes.byref(h)))
+        self._h = h
+        self.slabs = []
+        for r in range(int(nslabs)):
+            c = ctypes.c_void_p()
+            check(self.lib.bflbm_ring_slab(self._h, r, ctypes.byref(c)))
+            z0, z1 = (self.n[2] * r) // nslabs, (self.n[2] * (r + 1)) // nslabs
+            self.slabs.append(BinaryLBM._borrow(c, self.n, z0, z1, r, nslabs, self.params))
+        if schedule is not None:
+            code = {"two_pass": 0, "fused": 1, "auto": 2}.get(schedule, schedule)
+            check(self.lib.bflbm_ring_set_schedule(self._h, int(code)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.bflbm_ring_destroy(self._h)
+            self._h = None
+            for s in self.slabs:
+                s._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.params, k):
+                raise AttributeError(f"unknown model parameter {k!r}")
+            setattr(self.params, k, v)
+        check(self.lib.bflbm_ring_set_params(self._h, ctypes.byref(self.params)))
+
+    def LBM_init_mixture(self):
+        check(self.lib.bflbm_ring_init_mixture(self._h))
+
+    def LBM_init_stripe(self, frac):
+        check(self.lib.bflbm_ring_init_stripe(self._h, float(frac)))
+
+    def LBM_init_droplet(self, r):
+        check(self.lib.bflbm_ring_init_droplet(self._h, float(r)))
+
+    def LBM_init(self, f0, g0):
+        """f0, g0: full-lattice arrays (19, nz, ny, nx); every slab takes its planes."""
+        _check_array(f0, NVEL, (self.n[2], self.n[1], self.n[0]), "f0")
+        _check_array(g0, NVEL, (self.n[2], self.n[1], self.n[0]), "g0")
+        fab = make_fab((0, 0, 0), (self.n[0] - 1, self.n[1] - 1, self.n[2] - 1))
+        for s in self.slabs:
+            s.upload(f0, g0, fab)
+        check(self.lib.bflbm_ring_commit_upload(self._h, 1))
+
+    def LBM_timestep(self, nsteps=1):
+        check(self.lib.bflbm_ring_step(self._h, int(nsteps)))
+
+    def _gather(self, ncomp, call):
+        out = np.empty((ncomp, self.n[2], self.n[1], self.n[0]))
+        fab = make_fab((0, 0, 0), (self.n[0] - 1, self.n[1] - 1, self.n[2] - 1))
+        for s in self.slabs:
+            call(s, out, fab)
+        return out
+
+    def populations(self):
+        f = np.empty((NVEL, self.n[2], self.n[1], self.n[0])); g = np.empty_like(f)
+        fab = make_fab((0, 0, 0), (self.n[0] - 1, self.n[1] - 1, self.n[2] - 1))
+        for s in self.slabs:
+            s.populations(f, g, fab)
+        return f, g
+
+    def LBM_hydrovars_density(self):
+        return self._gather(NHYDROBAR, lambda s, o, fab: s.LBM_hydrovars_density(o, fab))
+
+    def LBM_hydrovars(self, ncomp=NHYDRO):
+        return self._gather(ncomp, lambda s, o, fab: s.LBM_hydrovars(o, fab, ncomp))
+
+    def thermal_noise(self):
+        fn = np.empty((NVEL, self.n[2], self.n[1], self.n[0])); gn = np.empty_like(fn)
+        fab = make_fab((0, 0, 0), (self.n[0] - 1, self.n[1] - 1, self.n[2] - 1))
+        for s in self.slabs:
+            s.thermal_noise(fn, gn, fab)
+        return fn, gn
+
+    def update_com(self):
+        s = (ctypes.c_double * 4)()
+        check(self.lib.bflbm_ring_com_sums(self._h, s))
+        s = np.array(list(s))
+        return s[1:] / s[0]
+
+    def mass(self):
+        r, p = ctypes.c_double(), ctypes.c_double()
+        check(self.lib.bflbm_ring_mass(self._h, ctypes.byref(r), ctypes.byref(p)))
+        return r.value, p.value
+
+    def sync(self):
+        check(self.lib.bflbm_ring_sync(self._h))
+
+    @property
+    def steps_done(self):
+        return self.slabs[0].steps_done
 
 
 def rng_site_normals(seed, site, noise_index):

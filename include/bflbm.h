@@ -141,6 +141,30 @@ int bflbm_halo_bytes(const bflbm_ctx* c, int kind, size_t* bytes_per_side);
 int bflbm_halo_pack(bflbm_ctx* c, int kind, int side, void* device_buf);
 int bflbm_halo_unpack(bflbm_ctx* c, int kind, int side, const void* device_buf);
 
+/* ---- Single-process ring of slabs (the reference runs as ONE process, USE_MPI=FALSE, GNUmakefile:16):
+ * nslabs z-slabs of one lattice, slab r on GPU devices[r % ndevices]; the +-z exchange of every step is
+ * done with device-to-device (peer, xGMI) copies on a second stream per slab and overlaps the interior
+ * planes.  nslabs == 1 is the plain single-GPU case.  Per-slab work (upload, download, observables,
+ * noise injection) goes through the slab's context from bflbm_ring_slab(); every bflbm_get_* /
+ * bflbm_upload_fg / bflbm_download_fg call only touches the cells of the given box that lie in that slab,
+ * so a driver simply loops over the slabs.  This is what include/bflbm_amrex.H drives. */
+typedef struct bflbm_ring bflbm_ring;
+int bflbm_ring_create(const bflbm_params* p, const int n[3], int nslabs, const int* devices, int ndevices, bflbm_ring** out);
+int bflbm_ring_destroy(bflbm_ring* r);
+int bflbm_ring_size(const bflbm_ring* r, int* nslabs);
+int bflbm_ring_slab(bflbm_ring* r, int slab, bflbm_ctx** ctx);
+int bflbm_ring_set_params(bflbm_ring* r, const bflbm_params* p);
+int bflbm_ring_set_schedule(bflbm_ring* r, int schedule);
+int bflbm_ring_init_mixture(bflbm_ring* r);
+int bflbm_ring_init_stripe(bflbm_ring* r, double frac);
+int bflbm_ring_init_droplet(bflbm_ring* r, double radius);
+/* after bflbm_upload_fg on every slab: exchange the uploaded faces, commit, exchange the state faces */
+int bflbm_ring_commit_upload(bflbm_ring* r, int reset_step_counter);
+int bflbm_ring_step(bflbm_ring* r, int nsteps);            /* LBM_timestep x nsteps on the whole lattice */
+int bflbm_ring_com_sums(bflbm_ring* r, double sums[4]);    /* update_com sums over all slabs */
+int bflbm_ring_mass(bflbm_ring* r, double* rho_sum, double* phi_sum);
+int bflbm_ring_sync(bflbm_ring* r);
+
 /* Materialise the per-step fields the reference keeps in MultiFabs, for the state
  * after the last completed step:
  *   hydrovsbar comps 0..8  (LBM_hydrovars_density, LBM_binary.H:315-354)

@@ -99,3 +99,12 @@ def test_legacy_arity_and_15_component_hydrovs():
 def test_restart_through_cpp_lbm_init_is_transparent():
     """LBM_init(geom, ..., mf0, mg0, ..., com_ref) with the populations just downloaded leaves every output unchanged."""
     assert _run_env({"LBM_RESTART_CHECK": "1"}, 10, 6, "droplet", 0, 2.0) == _run(10, 6, "droplet", 0, 2.0)
+
+
+@pytest.mark.parametrize("nslabs", [2, 3])
+def test_cpp_adapter_over_the_native_ring(nslabs):
+    """BFLBM_NSLABS: the same driver, the lattice split into z-slabs behind the unchanged LBM_* calls
+    (all slabs on the one GPU here; BFLBM_NGPUS places them on several)."""
+    for args in [(12, 6, "droplet", 1e-5, 2.0), (12, 5, "stripe", 0, 1.5)]:
+        assert _run_env({"BFLBM_NSLABS": str(nslabs)}, *args) == _run(*args)
+    assert _run_env({"BFLBM_NSLABS": str(nslabs), "LBM_RESTART_CHECK": "1"}, 12, 6, "droplet", 0, 2.0) == _run(12, 6, "droplet", 0, 2.0)

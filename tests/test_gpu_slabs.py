@@ -153,3 +153,54 @@ def test_distributed_driver_ranks_sharing_one_gpu(ob, world):
             _same(o["h"], ref.h[:, z0:z1], f"rank {r} hydrovs")
             np.testing.assert_allclose(o["com"], ref.com(), rtol=1e-12)
             np.testing.assert_allclose(o["mass"], [ref.hbar[0].sum(), ref.hbar[1].sum()], rtol=1e-12)
+
+
+@pytest.mark.parametrize("schedule", ["two_pass", "fused"])
+@pytest.mark.parametrize("nslabs,n", [(1, (8, 8, 8)), (2, (8, 8, 8)), (3, (10, 6, 13)), (4, (70, 9, 16))])
+def test_native_ring(pkg, ob, nslabs, n, schedule):
+    """bflbm_ring_*: the single-process ring inside the C-ABI (peer copies on a second stream overlapped
+    with the interior planes), all slabs on the one GPU of the box, against the single-box oracle."""
+    par = dict(kBT=1e-5, alpha0=2.0, seed=31)
+    ring = pkg.RingLBM(*n, nslabs=nslabs, devices=(0,), params=pkg.default_params(**par), schedule=schedule)
+    ref = ob.OracleLattice(*n, params=ob.default_params(**par))
+    ring.LBM_init_droplet(0.3)
+    ref.init_droplet(0.3)
+    ring.LBM_timestep(7)
+    for _ in range(7):
+        ref.timestep()
+    f, g = ring.populations()
+    _same(f, ref.f, "f")
+    _same(g, ref.g, "g")
+    _same(ring.LBM_hydrovars(), ref.h, "hydrovs")
+    _same(ring.thermal_noise()[0], ref.fn, "fnoise")
+    np.testing.assert_allclose(ring.update_com(), ref.com(), rtol=1e-12)
+    assert ring.steps_done == 7
+    # restart from populations through the ring (upload faces exchanged natively)
+    rng = np.random.default_rng(9)
+    f0 = ref.f * (1 + 0.01 * rng.standard_normal(ref.f.shape))
+    g0 = ref.g * (1 + 0.01 * rng.standard_normal(ref.g.shape))
+    ring.LBM_init(f0, g0)
+    ref.init_from(f0, g0)
+    ring.LBM_timestep(3)
+    for _ in range(3):
+        ref.timestep()
+    f, g = ring.populations()
+    _same(f, ref.f, "f after ring LBM_init")
+    _same(g, ref.g, "g after ring LBM_init")
+    ring.close()
+
+
+def test_native_ring_256_matches_single_context(pkg):
+    """Overlap hazards show up at size: 4 slabs of 256x256x64 vs the single 256^3 context, 12 steps."""
+    n = 256
+    a = pkg.BinaryLBM(n, n, n)
+    a.LBM_init_droplet(0.2)
+    a.LBM_timestep(12)
+    ha = a.LBM_hydrovars_density()
+    a.close()
+    r = pkg.RingLBM(n, n, n, nslabs=4, devices=(0,))
+    r.LBM_init_droplet(0.2)
+    r.LBM_timestep(12)
+    hr = r.LBM_hydrovars_density()
+    r.close()
+    assert np.array_equal(ha, hr)
