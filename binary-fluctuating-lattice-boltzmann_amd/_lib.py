@@ -82,6 +82,13 @@ SIGNATURES = {
     "bflbm_ring_com_sums": (ctypes.c_int, [_vp, _dp]),
     "bflbm_ring_mass": (ctypes.c_int, [_vp, _dp, _dp]),
     "bflbm_ring_sync": (ctypes.c_int, [_vp]),
+    "bflbm_ring_set_ref_state": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Fab)]),
+    "bflbm_ring_enable_ref_state": (ctypes.c_int, [_vp, ctypes.c_int, _dp]),
+    "bflbm_ring_prepare_ref": (ctypes.c_int, [_vp]),
+    "bflbm_set_ref_state": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Fab)]),
+    "bflbm_enable_ref_state": (ctypes.c_int, [_vp, ctypes.c_int, _dp]),
+    "bflbm_ref_state_active": (ctypes.c_int, [_vp, _P(ctypes.c_int)]),
+    "bflbm_set_com": (ctypes.c_int, [_vp, _dp]),
     "bflbm_get_hydrovsbar": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _P(Fab)]),
     "bflbm_get_hydrovs": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _P(Fab)]),
     "bflbm_get_noise": (ctypes.c_int, [_vp, _vp, _vp, _P(Fab)]),

@@ -7,6 +7,12 @@
 // usage: lbm_run_job <nx> [<ny> <nz>] <nsteps> <mixture|stripe|droplet> [kBT] [alpha0] [sync 0|1|2] [plot_root]
 // With plot_root the final hydrovs frame, the noise and the f/g checkpoints are written as AMReX
 // plotfiles named like the reference's (main_run_job.cpp:42, :400-409; Debug.H:390-408).
+//
+// Built a second time with -DUSE_REF_STATE (lbm_run_job_ref), like the reference's compile-time switch
+// (LBM_binary.H:12): the run then mirrors the noiseSwitch flow of main_run_job.cpp:216-235, :253-270 --
+// equilibrium fields into rho_eq/phi_eq/rhot_eq (here: the initial state's hydrovs 0, 1, 5 instead of
+// files), com_ref from update_com(rho_eq) (here moved by (2.6,-1.4,3.3) so that the lookup is shifted),
+// continuation through LBM_init, then the time loop.
 #include <algorithm>
 #include <array>
 #include <cctype>
@@ -18,6 +24,7 @@
 
 #include "host_multifab.H"
 using namespace bflbm::host;
+// #define USE_REF_STATE  -- from the command line (-DUSE_REF_STATE), before the adapter like before LBM_binary.H
 #include "../../include/bflbm_amrex.H"
 #include "../../include/bflbm_plotfile.H"
 
@@ -60,6 +67,26 @@ int main(int argc, char* argv[]) {
   else if (system == "droplet") LBM_init_droplet(0.2, geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq);
   else { std::fprintf(stderr, "unknown system %s\n", system.c_str()); return 2; }
   std::printf("LB initialized with alpha0 = %g and T = %g, %zu boxes of max size %d\n", (double)alpha0, (double)kBT, ba.size(), max_grid_size);
+#ifdef USE_REF_STATE
+  {
+    bflbm::materialize(geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs);
+    for (MFIter mfi(hydrovs); mfi.isValid(); ++mfi) {
+      const Box& v = mfi.validbox();
+      for (int z = v.smallEnd(2); z <= v.bigEnd(2); ++z) for (int y = v.smallEnd(1); y <= v.bigEnd(1); ++y) for (int x = v.smallEnd(0); x <= v.bigEnd(0); ++x) {
+        rho_eq[mfi](x, y, z, 0) = hydrovs[mfi](x, y, z, 0);
+        phi_eq[mfi](x, y, z, 0) = hydrovs[mfi](x, y, z, 1);
+        rhot_eq[mfi](x, y, z, 0) = hydrovs[mfi](x, y, z, 5);
+      }
+    }
+    bflbm::invalidate_ref_state();                          // the fields changed after the first LBM_* call
+    update_com(geom, com_ref[0], rho_eq, true);             // main_run_job.cpp:230-233
+    const double off[3] = {2.6, -1.4, 3.3};
+    for (int d = 0; d < 3; ++d) com_ref[0][d] -= off[d];
+    MultiFab f0(ba, nvel, nghost, domain), g0(ba, nvel, nghost, domain);
+    bflbm::pull_field(geom, bflbm::F_POPS, f0, &g0);
+    LBM_init(geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs, f0, g0, rho_eq, phi_eq, rhot_eq, com_ref);   // :269-270
+  }
+#endif
 
   for (int step = 1; step <= nsteps; ++step) {              // :335-339
     if (legacy) LBM_timestep(geom, fold, gold, fnew, gnew, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq);
@@ -85,6 +112,7 @@ int main(int argc, char* argv[]) {
   if (nz > 2) std::printf("ufz(0,0,2) %.17g\n", hydrovs.at(0, 0, 2, 4));
   std::printf("fold(1,1,1,3) %.17g gold(1,1,1,7) %.17g\n", fold.at(1 % nx, 1 % ny, 1 % nz, 3), gold.at(1 % nx, 1 % ny, 1 % nz, 7));
   std::printf("com %.12g %.12g %.12g\n", com[0], com[1], com[2]);
+  std::printf("fnoise(1,2,3,4) %.17g gnoise(3,2,1,18) %.17g\n", fnoisevs.at(1 % nx, 2 % ny, 3 % nz, 4), gnoisevs.at(3 % nx, 2 % ny, 1 % nz, 18));
   // ghost cells must hold the periodic image after the adapter's FillBoundary
   MFIter it(hydrovsbar);
   std::printf("ghost_check %d\n", (int)(hydrovsbar[it](-1, 0, 0, 0) == hydrovsbar.at(nx - 1, 0, 0, 0)));

@@ -97,6 +97,14 @@ struct bflbm_ctx {
   bool step_open = false;
   bool density_valid = false;   // rho/phi arrays hold the densities of the resident state
   size_t bytes = 0;
+  // USE_REF_STATE (LBM_binary.H:12, :92-107): noise amplitudes from an equilibrium state
+  double* ref[3] = {nullptr, nullptr, nullptr};   // rho_eq, phi_eq, rhot_eq over the GLOBAL lattice
+  bool ref_on = false;
+  double com_ref[3] = {0., 0., 0.};
+  int ref_kind = 0;             // what the call that made the resident state hands to thermal_noise:
+  long long ref_kind_step = -1; //   0 COM - com_ref (:588, :653), 1 zero (:690, :739), 2 absolute COM (:623-625)
+  double com[3] = {0., 0., 0.}; // global centre of mass (update_com) of the resident state
+  bool com_valid = false;
 };
 
 namespace {
@@ -113,18 +121,36 @@ int launch_density(bflbm_ctx* c, int pa, int pb) {
   return 0;
 }
 
+inline bool ref_active(const bflbm_ctx* c) { return c->ref_on && c->dp.noise_on && !c->inject; }
+
+// shift of the reference-state lookup for the noise of the resident state
+RefState ref_state(const bflbm_ctx* c) {
+  RefState R;
+  R.rho = c->ref[0]; R.phi = c->ref[1]; R.rhot = c->ref[2];
+  R.on = ref_active(c) ? 1 : 0;
+  R.sx = R.sy = R.sz = 0;
+  if (!R.on) return R;
+  const int kind = (c->steps == c->ref_kind_step) ? c->ref_kind : 0;
+  if (kind == 1) return R;
+  double rel[3];
+  for (int d = 0; d < 3; ++d) rel[d] = c->com[d] - (kind == 0 ? c->com_ref[d] : 0.);
+  R.sx = (int)rel[0]; R.sy = (int)rel[1]; R.sz = (int)rel[2];     // static_cast<int>, :94-96
+  return R;
+}
+
 int launch_collide(bflbm_ctx* c, int pa, int pb) {
   if (pb <= pa) return 0;
+  const RefState Rf = ref_state(c);
   const double* src = c->S[c->cur];
   double* dst = c->S[1 - c->cur];
   const uint32_t idx = (uint32_t)c->steps;
   dim3 g = plane_grid(c, pb - pa), b(256);
   if (c->inject)
-    hipLaunchKernelGGL((k_collide<true, true>), g, b, 0, c->stream, src, dst, c->rho, c->phi, c->injf, c->injg, c->G, c->dp, pa, idx);
+    hipLaunchKernelGGL((k_collide<true, true>), g, b, 0, c->stream, src, dst, c->rho, c->phi, c->injf, c->injg, c->G, c->dp, pa, idx, Rf);
   else if (c->dp.noise_on)
-    hipLaunchKernelGGL((k_collide<true, false>), g, b, 0, c->stream, src, dst, c->rho, c->phi, c->injf, c->injg, c->G, c->dp, pa, idx);
+    hipLaunchKernelGGL((k_collide<true, false>), g, b, 0, c->stream, src, dst, c->rho, c->phi, c->injf, c->injg, c->G, c->dp, pa, idx, Rf);
   else
-    hipLaunchKernelGGL((k_collide<false, false>), g, b, 0, c->stream, src, dst, c->rho, c->phi, c->injf, c->injg, c->G, c->dp, pa, idx);
+    hipLaunchKernelGGL((k_collide<false, false>), g, b, 0, c->stream, src, dst, c->rho, c->phi, c->injf, c->injg, c->G, c->dp, pa, idx, Rf);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -139,6 +165,7 @@ int launch_fused(bflbm_ctx* c, int pa, int pb) {
 // is VALU-bound (Philox + Box-Muller) and the independent 256-thread workgroups of the two-pass
 // schedule use the vector units better (measured 4690 vs 4220 MLUPS at 256^3).
 inline int resolved_schedule(const bflbm_ctx* c) {
+  if (ref_active(c)) return 0;                   // needs the densities and their centre of mass first
   if (c->schedule != 2) return c->schedule;
   return (c->dp.noise_on || c->inject) ? 0 : 1;
 }
@@ -315,6 +342,7 @@ int bflbm_destroy(bflbm_ctx* c) {
   if (c->injf) hipFree(c->injf);
   if (c->injg) hipFree(c->injg);
   if (c->partial) hipFree(c->partial);
+  for (int k = 0; k < 3; ++k) if (c->ref[k]) hipFree(c->ref[k]);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
@@ -364,7 +392,9 @@ static int run_init(bflbm_ctx* c, int mode, const double* rho_ext_host, size_t n
   hipLaunchKernelGGL(k_init, plane_grid(c, c->G.nzs), dim3(256), 0, c->stream, c->S[c->cur], scratch, c->G, mode, rho_c, phi_c, rho_t, 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
-  c->steps = 0; c->density_valid = false; c->step_open = false;
+  c->steps = 0; c->density_valid = false; c->step_open = false; c->com_valid = false;
+  c->ref_kind = (mode == 0) ? 2 : 1;             // thermal_noise gets the absolute COM (:623-625) or zero (:690, :739)
+  c->ref_kind_step = 0;
   return 0;
 }
 
@@ -450,7 +480,8 @@ int bflbm_commit_upload(bflbm_ctx* c, int reset) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (reset) c->steps = 0;
-  c->density_valid = false; c->step_open = false;
+  c->density_valid = false; c->step_open = false; c->com_valid = false;
+  c->ref_kind = 0; c->ref_kind_step = c->steps;  // LBM_init: COM relative to com_ref (:651-654)
   return 0;
 }
 
@@ -467,10 +498,12 @@ int bflbm_download_fg(bflbm_ctx* c, double* f, double* g, const bflbm_fab* box) 
 }
 
 // ---- time stepping --------------------------------------------------------------------
+static int prepare_ref(bflbm_ctx* c);
 int bflbm_step_boundary(bflbm_ctx* c) {
   if (!c) return fail("null context");
   if (c->step_open) return fail("step already open");
   HIP_TRY(hipSetDevice(c->dom.device));
+  if (prepare_ref(c)) return 1;
   c->step_open = true;
   const int lo = own_lo(c), hi = own_hi(c);
   if (c->G.zwrap) return 0;                      // single slab: everything is "interior"
@@ -501,6 +534,7 @@ int bflbm_step_finish(bflbm_ctx* c) {
   c->steps += 1;
   c->step_open = false;
   c->density_valid = false;
+  c->com_valid = false;
   if (c->inject) c->inject = false;              // injected noise feeds exactly one step
   return 0;
 }
@@ -559,13 +593,15 @@ static int observe(bflbm_ctx* c, int what, int ncomp_out, double* dst, double* d
   if (c->step_open) return fail("observables requested inside an open step");
   HIP_TRY(hipSetDevice(c->dom.device));
   if (what == 2 && ensure_density(c)) return 1;
+  if (what != 0 && prepare_ref(c)) return 1;
+  const RefState Rf = ref_state(c);
   double* out = c->S[1 - c->cur];
   dim3 g = plane_grid(c, c->nzl), b(256);
   const uint32_t idx = (uint32_t)c->steps;
   const int inj = c->inject ? 1 : 0;
-  if (what == 0) hipLaunchKernelGGL((k_observe<0>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj);
-  if (what == 1) hipLaunchKernelGGL((k_observe<1>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj);
-  if (what == 2) hipLaunchKernelGGL((k_observe<2>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj);
+  if (what == 0) hipLaunchKernelGGL((k_observe<0>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj, Rf);
+  if (what == 1) hipLaunchKernelGGL((k_observe<1>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj, Rf);
+  if (what == 2) hipLaunchKernelGGL((k_observe<2>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj, Rf);
   HIP_TRY(hipGetLastError());
   const long long ovol = (long long)c->nzl * c->G.plane;
   if (what == 1) {
@@ -632,6 +668,62 @@ int bflbm_mass(bflbm_ctx* c, double* rho_sum, double* phi_sum) {
   double r[5];
   if (reduce5(c, r)) return 1;
   *rho_sum = r[0]; *phi_sum = r[1];
+  return 0;
+}
+
+// ---- reference-state noise (USE_REF_STATE) ------------------------------------------------------
+// the centre of mass the noise of the resident state needs (LBM_binary.H:585-588); a single slab
+// reduces it itself, a slab of a decomposed lattice gets the global one from its driver
+static int prepare_ref(bflbm_ctx* c) {
+  if (!ref_active(c)) return 0;
+  const int kind = (c->steps == c->ref_kind_step) ? c->ref_kind : 0;
+  if (kind == 1 || c->com_valid) return 0;
+  if (!c->G.zwrap) return fail("reference-state noise on a slab: hand over the global centre of mass of the resident state first (bflbm_set_com)");
+  double r[5];
+  if (reduce5(c, r)) return 1;
+  for (int d = 0; d < 3; ++d) c->com[d] = r[2 + d] / r[0];
+  c->com_valid = true;
+  return 0;
+}
+
+int bflbm_set_ref_state(bflbm_ctx* c, const double* rho_eq, const double* phi_eq, const double* rhot_eq, const bflbm_fab* box) {
+  if (!c || !rho_eq || !phi_eq || !rhot_eq) return fail("null argument");
+  if (check_fab(box)) return 1;
+  HIP_TRY(hipSetDevice(c->dom.device));
+  const size_t nb = (size_t)c->G.plane * c->G.nz * sizeof(double);
+  const double* src[3] = { rho_eq, phi_eq, rhot_eq };
+  // the whole lattice on every slab: the lookup is shifted by the drifting centre of mass
+  bflbm_domain whole = c->dom; whole.z0 = 0; whole.z1 = c->G.nz;
+  const bflbm_domain keep = c->dom;
+  for (int k = 0; k < 3; ++k) {
+    if (!c->ref[k]) { HIP_TRY(hipMalloc((void**)&c->ref[k], nb)); HIP_TRY(hipMemsetAsync(c->ref[k], 0, nb, c->stream)); c->bytes += nb; }
+    c->dom = whole;
+    const int rc = copy_fab(c, const_cast<double*>(src[k]), box, 1, c->ref[k], 0, 0, true);
+    c->dom = keep;
+    if (rc) return 1;
+  }
+  return 0;
+}
+
+int bflbm_enable_ref_state(bflbm_ctx* c, int on, const double com_ref[3]) {
+  if (!c) return fail("null context");
+  if (on && (!c->ref[0] || !com_ref)) return fail("bflbm_enable_ref_state: upload the reference state first (bflbm_set_ref_state) and give com_ref");
+  c->ref_on = on != 0;
+  if (on) for (int d = 0; d < 3; ++d) c->com_ref[d] = com_ref[d];
+  return 0;
+}
+
+int bflbm_ref_state_active(const bflbm_ctx* c, int* active) {
+  if (!c || !active) return fail("null argument");
+  *active = ref_active(c) ? 1 : 0;
+  return 0;
+}
+
+int bflbm_set_com(bflbm_ctx* c, const double com[3]) {
+  if (!c || !com) return fail("null argument");
+  if (c->step_open) return fail("bflbm_set_com inside an open step");
+  for (int d = 0; d < 3; ++d) c->com[d] = com[d];
+  c->com_valid = true;
   return 0;
 }
 
@@ -865,11 +957,40 @@ int bflbm_ring_commit_upload(bflbm_ring* r, int reset) {
   return bflbm_ring_sync(r);
 }
 
+int bflbm_ring_com_sums(bflbm_ring* r, double sums[4]);
+// reference-state noise: the slabs need the GLOBAL centre of mass of the resident state
+static int ring_prepare_ref(bflbm_ring* r) {
+  bflbm_ctx* c0 = r->ctx[0];
+  if (!ref_active(c0) || c0->com_valid) return 0;
+  if (c0->steps == c0->ref_kind_step && c0->ref_kind == 1) return 0;
+  double s[4];
+  if (bflbm_ring_com_sums(r, s)) return 1;
+  const double com[3] = { s[1] / s[0], s[2] / s[0], s[3] / s[0] };
+  for (bflbm_ctx* c : r->ctx) if (bflbm_set_com(c, com)) return 1;
+  return 0;
+}
+
+int bflbm_ring_set_ref_state(bflbm_ring* r, const double* rho_eq, const double* phi_eq, const double* rhot_eq, const bflbm_fab* box) {
+  if (!r) return fail("null ring");
+  for (bflbm_ctx* c : r->ctx) if (bflbm_set_ref_state(c, rho_eq, phi_eq, rhot_eq, box)) return 1;
+  return 0;
+}
+int bflbm_ring_enable_ref_state(bflbm_ring* r, int on, const double com_ref[3]) {
+  if (!r) return fail("null ring");
+  for (bflbm_ctx* c : r->ctx) if (bflbm_enable_ref_state(c, on, com_ref)) return 1;
+  return 0;
+}
+int bflbm_ring_prepare_ref(bflbm_ring* r) {     // before reading noise / hydrovs of the slabs
+  if (!r) return fail("null ring");
+  return r->ctx.size() > 1 ? ring_prepare_ref(r) : 0;
+}
+
 int bflbm_ring_step(bflbm_ring* r, int nsteps) {
   if (!r) return fail("null ring");
   if (nsteps < 0) return fail("nsteps < 0");
   if (r->ctx.size() == 1) return bflbm_step(r->ctx[0], nsteps);
   for (int s = 0; s < nsteps; ++s) {
+    if (ring_prepare_ref(r)) return 1;
     for (bflbm_ctx* c : r->ctx) if (bflbm_step_boundary(c)) return 1;
     if (ring_exchange(r, BFLBM_HALO_NEXT)) return 1;       // comm streams: copies + unpack ...
     for (bflbm_ctx* c : r->ctx) if (bflbm_step_interior(c)) return 1;   // ... while the main streams sweep the interior

@@ -213,7 +213,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
         for (int k = 0; k < 3; ++k) { fn3[k] = nb_f[(1 + k) * nvol + no]; gn3[k] = nb_g[(1 + k) * nvol + no]; }
       } else if (MODE == 1) {
         site = global_site(G, x, y, pc);
-        d_noise_amp(P, r, ph, NA);
+        d_noise_amp(P, r, ph, r + ph, NA);
         d_noise_head(P, NA, site, noise_index, fn3, n3);
 #pragma unroll
         for (int k = 0; k < 3; ++k) gn3[k] = -fn3[k];

@@ -81,6 +81,30 @@ __device__ __forceinline__ uint64_t global_site(const Geo& G, int x, int y, int 
   return (uint64_t)x + (uint64_t)G.nx*((uint64_t)y + (uint64_t)G.ny*(uint64_t)gz);
 }
 
+// USE_REF_STATE (LBM_binary.H:92-107): noise amplitudes from equilibrium fields covering the GLOBAL
+// lattice, looked up at the site shifted by the truncated relative centre of mass.
+struct RefState {
+  const double* rho; const double* phi; const double* rhot;
+  int on;
+  int sx, sy, sz;      // static_cast<int>(pos_com_relative[d])
+};
+__device__ __forceinline__ void noise_state(const RefState& Rf, const Geo& G, int x, int y, int p,
+                                            double r, double ph, double& ar, double& ap, double& at) {
+  if (!Rf.on) { ar = r; ap = ph; at = r + ph; return; }
+  int gz = G.z0 + (p - G.H);
+  if (gz < 0) gz += G.nz;
+  if (gz >= G.nz) gz -= G.nz;
+  int xs = x - Rf.sx, ys = y - Rf.sy, zs = gz - Rf.sz;
+  if (xs < 0) xs += G.nx;                        // one wrap each way, like the reference (:98-103)
+  if (xs > G.nx - 1) xs -= G.nx;
+  if (ys < 0) ys += G.ny;
+  if (ys > G.ny - 1) ys -= G.ny;
+  if (zs < 0) zs += G.nz;
+  if (zs > G.nz - 1) zs -= G.nz;
+  const long long o = (long long)xs + (long long)G.nx*((long long)ys + (long long)G.ny*(long long)zs);
+  ar = Rf.rho[o]; ap = Rf.phi[o]; at = Rf.rhot[o];
+}
+
 #define BFLBM_SITE_FROM_BLOCK()                                         \
   const long long s_ = (long long)blockIdx.x*blockDim.x + threadIdx.x;  \
   if (s_ >= G.plane) return;                                            \
@@ -108,7 +132,7 @@ template <bool NOISE, bool INJECT>
 __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const double* __restrict__ S, double* __restrict__ D,
                                                  const double* __restrict__ rho, const double* __restrict__ phi,
                                                  const double* __restrict__ injf, const double* __restrict__ injg,
-                                                 Geo G, DevParams P, int p0, uint32_t noise_index) {
+                                                 Geo G, DevParams P, int p0, uint32_t noise_index, RefState Rf) {
   BFLBM_SITE_FROM_BLOCK();
   SiteIdx I; site_index(G, x, y, p, I);
   double fs[Q], gs[Q];
@@ -126,7 +150,9 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
 #pragma unroll
     for (int a = 0; a < Q; ++a) { fn[a] = injf[a*nvol + no]; gn[a] = injg[a*nvol + no]; }
   } else if (NOISE) {
-    d_noise(P, r, ph, global_site(G, x, y, p), noise_index, fn, gn);
+    double ar, ap, at;
+    noise_state(Rf, G, x, y, p, r, ph, ar, ap, at);
+    d_noise(P, ar, ap, at, global_site(G, x, y, p), noise_index, fn, gn);
   } else {
 #pragma unroll
     for (int a = 0; a < Q; ++a) { fn[a] = 0.; gn[a] = 0.; }
@@ -228,7 +254,8 @@ template <int WHAT>
 __global__ void __launch_bounds__(256) k_observe(const double* __restrict__ S, const double* __restrict__ rho,
                                                  const double* __restrict__ phi, const double* __restrict__ injf,
                                                  const double* __restrict__ injg, double* __restrict__ out,
-                                                 Geo G, DevParams P, int p0, uint32_t noise_index, int ncomp, int inject) {
+                                                 Geo G, DevParams P, int p0, uint32_t noise_index, int ncomp, int inject,
+                                                 RefState Rf) {
   BFLBM_SITE_FROM_BLOCK();
   SiteIdx I; site_index(G, x, y, p, I);
   double fs[Q], gs[Q];
@@ -255,7 +282,9 @@ __global__ void __launch_bounds__(256) k_observe(const double* __restrict__ S, c
 #pragma unroll
     for (int a = 0; a < Q; ++a) { fn[a] = injf[a*ovol + oo]; gn[a] = injg[a*ovol + oo]; }
   } else if (P.noise_on) {
-    d_noise(P, r, ph, global_site(G, x, y, p), noise_index, fn, gn);
+    double ar, ap, at;
+    noise_state(Rf, G, x, y, p, r, ph, ar, ap, at);
+    d_noise(P, ar, ap, at, global_site(G, x, y, p), noise_index, fn, gn);
   } else {
 #pragma unroll
     for (int a = 0; a < Q; ++a) { fn[a] = 0.; gn[a] = 0.; }

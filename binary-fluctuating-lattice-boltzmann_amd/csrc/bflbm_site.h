@@ -271,8 +271,9 @@ __device__ __forceinline__ int d_noise_group(int a) {   // modes 4..18 -> index 
   return (a == 4 || (a >= 10 && a <= 12)) ? 0 : (a == 5 || a == 17) ? 1 : (a == 6 || a == 18) ? 2
        : (a >= 7 && a <= 9) ? 3 : (a >= 13 && a <= 15) ? 4 : 5;
 }
-__device__ __forceinline__ void d_noise_amp(const DevParams& P, double rho, double phi, NoiseAmp& A) {
-  const double rhot = rho + phi;
+// rho, phi, rhot: the state the amplitudes are taken from -- the site's own densities with
+// rhot = rho + phi (LBM_binary.H:109-111) or the reference state under USE_REF_STATE (:92-107).
+__device__ __forceinline__ void d_noise_amp(const DevParams& P, double rho, double phi, double rhot, NoiseAmp& A) {
   A.sj = sqrt(P.amp_j * fabs(rho*phi/rhot));
   const double arho = fabs(rho), aphi = fabs(phi);
   const int rep[6] = {4, 5, 6, 7, 13, 16};
@@ -308,9 +309,9 @@ __device__ __forceinline__ void d_noise_g(const DevParams& P, const NoiseAmp& A,
   for (int a = 4; a < Q; ++a) gn[a] = A.sg[d_noise_group(a)] * (double)nrm[a-4];
 }
 // all 38 noise moments (two-pass schedule, observables)
-__device__ __forceinline__ void d_noise(const DevParams& P, double rho, double phi, uint64_t site,
+__device__ __forceinline__ void d_noise(const DevParams& P, double rho, double phi, double rhot, uint64_t site,
                                         uint32_t noise_index, double (&fn)[Q], double (&gn)[Q]) {
-  NoiseAmp A; d_noise_amp(P, rho, phi, A);
+  NoiseAmp A; d_noise_amp(P, rho, phi, rhot, A);
   double fn3[3]; float n3;
   d_noise_head(P, A, site, noise_index, fn3, n3);
   d_noise_f(P, A, site, noise_index, fn3, n3, fn);

@@ -240,6 +240,31 @@ class BinaryLBM:
         check(self.lib.bflbm_mass(self._h, ctypes.byref(r), ctypes.byref(p)))
         return r.value, p.value
 
+    # -- reference-state noise: the reference's USE_REF_STATE build (LBM_binary.H:12, :92-107) ---------
+    def set_ref_state(self, rho_eq, phi_eq, rhot_eq, com_ref, fab=None):
+        """Equilibrium fields over the GLOBAL lattice (nz, ny, nx) (main_run_job.cpp:216-235) and the
+        reference centre of mass com_ref[0]; noise amplitudes then come from them."""
+        n = self.n
+        fab = fab if fab is not None else make_fab((0, 0, 0), (n[0] - 1, n[1] - 1, n[2] - 1))
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (rho_eq, phi_eq, rhot_eq)]
+        check(self.lib.bflbm_set_ref_state(self._h, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), ctypes.byref(fab)))
+        c = (ctypes.c_double * 3)(*[float(v) for v in com_ref])
+        check(self.lib.bflbm_enable_ref_state(self._h, 1, c))
+
+    def disable_ref_state(self):
+        check(self.lib.bflbm_enable_ref_state(self._h, 0, None))
+
+    @property
+    def ref_state_active(self):
+        a = ctypes.c_int()
+        check(self.lib.bflbm_ref_state_active(self._h, ctypes.byref(a)))
+        return bool(a.value)
+
+    def set_com(self, com):
+        """Global centre of mass of the resident state, for a slab of a decomposed lattice."""
+        c = (ctypes.c_double * 3)(*[float(v) for v in com])
+        check(self.lib.bflbm_set_com(self._h, c))
+
     # -- halo exchange plumbing (used by slab.SlabLattice) ---------------------------------------
     def halo_bytes(self, kind=_lib.HALO_STATE):
         n = ctypes.c_size_t()
@@ -361,9 +386,19 @@ class RingLBM:
         return self._gather(NHYDROBAR, lambda s, o, fab: s.LBM_hydrovars_density(o, fab))
 
     def LBM_hydrovars(self, ncomp=NHYDRO):
+        check(self.lib.bflbm_ring_prepare_ref(self._h))
         return self._gather(ncomp, lambda s, o, fab: s.LBM_hydrovars(o, fab, ncomp))
 
+    def set_ref_state(self, rho_eq, phi_eq, rhot_eq, com_ref):
+        n = self.n
+        fab = make_fab((0, 0, 0), (n[0] - 1, n[1] - 1, n[2] - 1))
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (rho_eq, phi_eq, rhot_eq)]
+        check(self.lib.bflbm_ring_set_ref_state(self._h, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), ctypes.byref(fab)))
+        c = (ctypes.c_double * 3)(*[float(v) for v in com_ref])
+        check(self.lib.bflbm_ring_enable_ref_state(self._h, 1, c))
+
     def thermal_noise(self):
+        check(self.lib.bflbm_ring_prepare_ref(self._h))
         fn = np.empty((NVEL, self.n[2], self.n[1], self.n[0])); gn = np.empty_like(fn)
         fab = make_fab((0, 0, 0), (self.n[0] - 1, self.n[1] - 1, self.n[2] - 1))
         for s in self.slabs:

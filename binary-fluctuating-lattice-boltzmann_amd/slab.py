@@ -31,9 +31,17 @@ class _Protocol:
         self.engine = engine
 
     # subclasses implement _exchange(kind, pack=True)
+    def _prepare_ref(self):
+        """Reference-state noise (USE_REF_STATE): the slab needs the GLOBAL centre of mass of the
+        resident state (LBM_binary.H:585-588) before its noise is drawn."""
+        e = self.engine
+        if getattr(e, "ref_state_active", False):
+            e.set_com(self.update_com())
+
     def LBM_timestep(self, nsteps=1):
         e = self.engine
         for _ in range(int(nsteps)):
+            self._prepare_ref()
             e.step_boundary()
             self._post(_lib.HALO_NEXT)
             e.step_interior()
@@ -138,10 +146,16 @@ class SlabLattice(_Protocol):
         return self.engine.LBM_hydrovars_density(*a, **k)
 
     def LBM_hydrovars(self, *a, **k):
+        self._prepare_ref()
         return self.engine.LBM_hydrovars(*a, **k)
 
     def thermal_noise(self, *a, **k):
+        self._prepare_ref()
         return self.engine.thermal_noise(*a, **k)
+
+    def set_ref_state(self, rho_eq, phi_eq, rhot_eq, com_ref):
+        """Global equilibrium fields (nz, ny, nx) on every rank."""
+        self.engine.set_ref_state(rho_eq, phi_eq, rhot_eq, com_ref)
 
     def update_com(self):
         """update_com (LBM_hydrovs.H:26-60) with the four .sum() reductions as one all-reduce."""
@@ -223,8 +237,19 @@ class LocalSlabRing:
             e.halo_unpack(kind, 1, bufs[r][3].data_ptr())
         self._sync_all()
 
+    def _prepare_ref(self):
+        if getattr(self.engines[0], "ref_state_active", False):
+            com = self.update_com()
+            for e in self.engines:
+                e.set_com(com)
+
+    def set_ref_state(self, rho_eq, phi_eq, rhot_eq, com_ref):
+        for e in self.engines:
+            e.set_ref_state(rho_eq, phi_eq, rhot_eq, com_ref)
+
     def LBM_timestep(self, nsteps=1):
         for _ in range(int(nsteps)):
+            self._prepare_ref()
             for e in self.engines:
                 e.step_boundary()
             for e in self.engines:
@@ -273,9 +298,11 @@ class LocalSlabRing:
         return self._gather(lambda e: e.LBM_hydrovars_density(), 9)
 
     def LBM_hydrovars(self):
+        self._prepare_ref()
         return self._gather(lambda e: e.LBM_hydrovars(), 22)
 
     def thermal_noise(self):
+        self._prepare_ref()
         nx, ny, nz = self.n
         f = np.empty((19, nz, ny, nx)); g = np.empty_like(f)
         for e in self.engines:

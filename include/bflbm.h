@@ -164,6 +164,11 @@ int bflbm_ring_step(bflbm_ring* r, int nsteps);            /* LBM_timestep x nst
 int bflbm_ring_com_sums(bflbm_ring* r, double sums[4]);    /* update_com sums over all slabs */
 int bflbm_ring_mass(bflbm_ring* r, double* rho_sum, double* phi_sum);
 int bflbm_ring_sync(bflbm_ring* r);
+/* reference-state noise on the ring (see bflbm_set_ref_state); bflbm_ring_prepare_ref hands the global
+ * COM of the resident state to the slabs before their noise / hydrovs are read between steps. */
+int bflbm_ring_set_ref_state(bflbm_ring* r, const double* rho_eq, const double* phi_eq, const double* rhot_eq, const bflbm_fab* box);
+int bflbm_ring_enable_ref_state(bflbm_ring* r, int on, const double com_ref[3]);
+int bflbm_ring_prepare_ref(bflbm_ring* r);
 
 /* Materialise the per-step fields the reference keeps in MultiFabs, for the state
  * after the last completed step:
@@ -187,6 +192,23 @@ int bflbm_com_sums(bflbm_ctx* c, double sums[4]);
 
 /* Total of rho and phi over the slab (PrintMassConservation, Debug.H:232-249). */
 int bflbm_mass(bflbm_ctx* c, double* rho_sum, double* phi_sum);
+
+/* ---- Reference-state noise: the reference's compile-time USE_REF_STATE branch (LBM_binary.H:12,
+ * :92-107) as a run-time switch.  The noise amplitudes of thermal_noise are then taken from the
+ * equilibrium fields rho_eq, phi_eq, rhot_eq (main_run_job.cpp:216-235) at the site shifted by
+ * static_cast<int>(COM - com_ref), COM = update_com of the state the noise belongs to
+ * (LBM_binary.H:585-590).  Like the reference's callers, the state left by bflbm_init_stripe/_droplet
+ * uses a zero shift (:690, :739), the one left by bflbm_init_mixture the absolute COM (:623-625),
+ * uploaded states (LBM_init) and every later step COM - com_ref (:651-654, :588).
+ * bflbm_set_ref_state: per-box upload of the three one-component fields; they cover the GLOBAL
+ * lattice on every slab.  While active the two-pass schedule is used (the shift needs the densities
+ * of the whole lattice before the collision) and a slab of a decomposed lattice must be given the
+ * global COM of the resident state with bflbm_set_com before each step (the ring and the python slab
+ * driver do that; a single slab reduces it itself). */
+int bflbm_set_ref_state(bflbm_ctx* c, const double* rho_eq, const double* phi_eq, const double* rhot_eq, const bflbm_fab* box);
+int bflbm_enable_ref_state(bflbm_ctx* c, int on, const double com_ref[3]);
+int bflbm_ref_state_active(const bflbm_ctx* c, int* active);   /* on, kBT != 0 and no injected noise pending */
+int bflbm_set_com(bflbm_ctx* c, const double com[3]);
 
 int bflbm_sync(bflbm_ctx* c);
 

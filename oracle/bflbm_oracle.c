@@ -317,24 +317,42 @@ void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
 }
 
 /* ------------------------------------------------------------------ */
-/* thermal_noise, LBM_binary.H:73-132 (non-USE_REF_STATE branch, :109-111).
- * Draw count per site as in the reference: 3 + 2*15 normals.
+/* thermal_noise, LBM_binary.H:73-132.  Draw count per site as in the reference: 3 + 2*15 normals.
  * gz0 = global z of local plane 0 and gnz = global nz (slab tests; the site id that keys the
- * random stream is the GLOBAL lattice index). */
-void orc_thermal_noise_slab(const orc_params* p, int nx, int ny, int nz, int gz0, int gnz,
-                            const double* hbar, uint32_t noise_index,
-                            double* fn, double* gn) {
+ * random stream is the GLOBAL lattice index).
+ * ref == NULL: the shipped branch (:109-111), rho,phi from hydrovsbar, rhot = rho+phi.
+ * ref != NULL: the USE_REF_STATE branch (:92-107): rho,phi,rhot from the equilibrium fields
+ * ref[0..2] (global lattice, one component each) at the site shifted by the truncated relative
+ * centre of mass, wrapped once into the domain. */
+static void thermal_noise_impl(const orc_params* p, int nx, int ny, int nz, int gz0, int gnz,
+                               const double* hbar, const double* const* ref, const double* pos_com_relative,
+                               uint32_t noise_index, double* fn, double* gn) {
   const double tau_f_bar = 1./(p->tau_f+0.5);
   const double tau_g_bar = tau_f_bar;                /* :80 (sic) */
   const double tau_f_bar2 = tau_f_bar*tau_f_bar;
   const double tau_g_bar2 = tau_g_bar*tau_g_bar;
   const double kBT = p->kBT, cs2 = p->cs2;
   for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
-    double rho = hbar[IDX(nx,ny,nz,0,x,y,z)];
-    double phi = hbar[IDX(nx,ny,nz,1,x,y,z)];
-    double rhot = rho + phi;
-    double nrm[36];
     int gz = (z + gz0) % gnz; if (gz < 0) gz += gnz;
+    double rho, phi, rhot;
+    if (ref) {
+      int x_shift = x - (int)pos_com_relative[0];     /* static_cast<int>: truncation, :94-96 */
+      int y_shift = y - (int)pos_com_relative[1];
+      int z_shift = gz - (int)pos_com_relative[2];
+      if (x_shift < 0) x_shift += nx;                 /* :98-103 */
+      if (x_shift > nx-1) x_shift -= nx;
+      if (y_shift < 0) y_shift += ny;
+      if (y_shift > ny-1) y_shift -= ny;
+      if (z_shift < 0) z_shift += gnz;
+      if (z_shift > gnz-1) z_shift -= gnz;
+      const size_t o = (size_t)x_shift + (size_t)nx*((size_t)y_shift + (size_t)ny*(size_t)z_shift);
+      rho = ref[0][o]; phi = ref[1][o]; rhot = ref[2][o];
+    } else {
+      rho = hbar[IDX(nx,ny,nz,0,x,y,z)];
+      phi = hbar[IDX(nx,ny,nz,1,x,y,z)];
+      rhot = rho + phi;
+    }
+    double nrm[36];
     uint64_t site = (uint64_t)x + (uint64_t)nx*((uint64_t)y + (uint64_t)ny*(uint64_t)gz);
     orc_site_normals(p->seed, site, noise_index, nrm);
     /* Assignment of the site's normals to modes (project-defined, like the stream itself):
@@ -353,6 +371,21 @@ void orc_thermal_noise_slab(const orc_params* p, int nx, int ny, int nz, int gz0
       gn[IDX(nx,ny,nz,a,x,y,z)] = sqrt(2.*(tau_g_bar - 0.5*tau_g_bar2)*kBT/cs2*B[a]*fabs(phi))*nrm[20 + (a-4)];
     }
   }
+}
+
+void orc_thermal_noise_slab(const orc_params* p, int nx, int ny, int nz, int gz0, int gnz,
+                            const double* hbar, uint32_t noise_index,
+                            double* fn, double* gn) {
+  thermal_noise_impl(p, nx, ny, nz, gz0, gnz, hbar, NULL, NULL, noise_index, fn, gn);
+}
+
+/* USE_REF_STATE branch on a slab: rho_eq, phi_eq, rhot_eq cover the GLOBAL lattice nx*ny*gnz. */
+void orc_thermal_noise_ref_slab(const orc_params* p, int nx, int ny, int nz, int gz0, int gnz,
+                                const double* rho_eq, const double* phi_eq, const double* rhot_eq,
+                                const double* pos_com_relative, uint32_t noise_index,
+                                double* fn, double* gn) {
+  const double* ref[3] = { rho_eq, phi_eq, rhot_eq };
+  thermal_noise_impl(p, nx, ny, nz, gz0, gnz, NULL, ref, pos_com_relative, noise_index, fn, gn);
 }
 
 void orc_thermal_noise(const orc_params* p, int nx, int ny, int nz,
@@ -578,6 +611,38 @@ void orc_timestep(const orc_params* p, int nx, int ny, int nz, uint32_t step_don
   orc_stream_push(nx,ny,nz, f, g, ftmp, gtmp);
   memcpy(f, ftmp, n); memcpy(g, gtmp, n);        /* MultiFab::Swap, :579-580 */
   orc_refresh(p, nx,ny,nz, step_done+1, f, g, hbar, fn, gn, h);
+}
+
+/* The same tail with the USE_REF_STATE noise branch; pos_com_relative as the caller of
+ * thermal_noise passes it (:588-590 relative to com_ref[0]; :623-625 absolute in LBM_init_mixture;
+ * zero in LBM_init_stripe/_droplet, :690, :739). */
+void orc_refresh_ref(const orc_params* p, int nx, int ny, int nz, uint32_t noise_index,
+                     const double* f, const double* g, double* hbar, double* fn, double* gn, double* h,
+                     const double* rho_eq, const double* phi_eq, const double* rhot_eq,
+                     const double* pos_com_relative) {
+  orc_hydrovars_density(p, nx,ny,nz, f, g, hbar);
+  orc_thermal_noise_ref_slab(p, nx,ny,nz, 0, nz, rho_eq, phi_eq, rhot_eq, pos_com_relative, noise_index, fn, gn);
+  orc_hydrovars(p, nx,ny,nz, f, g, hbar, fn, gn, h);
+}
+
+void orc_update_com(int nx, int ny, int nz, const double* hbar, double com[3]);
+
+/* LBM_timestep with USE_REF_STATE defined, LBM_binary.H:545-594 incl. :585-590. */
+void orc_timestep_ref(const orc_params* p, int nx, int ny, int nz, uint32_t step_done,
+                      double* f, double* g, double* ftmp, double* gtmp,
+                      double* hbar, double* fn, double* gn, double* h,
+                      const double* rho_eq, const double* phi_eq, const double* rhot_eq,
+                      const double* com_ref) {
+  size_t n = (size_t)Q*nx*ny*nz*sizeof(double);
+  orc_collide(p, nx,ny,nz, f, g, h, fn, gn);
+  orc_stream_push(nx,ny,nz, f, g, ftmp, gtmp);
+  memcpy(f, ftmp, n); memcpy(g, gtmp, n);
+  orc_hydrovars_density(p, nx,ny,nz, f, g, hbar);
+  double rel[3];
+  orc_update_com(nx,ny,nz, hbar, rel);               /* :587 */
+  for (int k = 0; k < 3; ++k) rel[k] -= com_ref[k];  /* :588 */
+  orc_thermal_noise_ref_slab(p, nx,ny,nz, 0, nz, rho_eq, phi_eq, rhot_eq, rel, step_done+1, fn, gn);
+  orc_hydrovars(p, nx,ny,nz, f, g, hbar, fn, gn, h);
 }
 
 /* Split form for injected-noise tests: collide+stream+densities only. */

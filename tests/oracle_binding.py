@@ -90,12 +90,36 @@ class OracleLattice:
         self.hbar = np.zeros((15,) + shp)
         self.h = np.zeros((22,) + shp)
         self.steps = 0
+        self.ref = None            # USE_REF_STATE: (rho_eq, phi_eq, rhot_eq, com_ref)
+
+    def set_ref_state(self, rho_eq, phi_eq, rhot_eq, com_ref):
+        """Switch to the reference's USE_REF_STATE build (LBM_binary.H:12, :92-107)."""
+        shp = self.f.shape[1:]
+        self.ref = tuple(np.ascontiguousarray(a, dtype=np.float64).reshape(shp) for a in (rho_eq, phi_eq, rhot_eq)) + \
+                   (np.ascontiguousarray(com_ref, dtype=np.float64),)
+
+    def _refresh_ref(self, rel):
+        nx, ny, nz = self.n
+        rel = np.ascontiguousarray(rel, dtype=np.float64)
+        lib().orc_refresh_ref(ctypes.byref(self.p), nx, ny, nz, ctypes.c_uint32(self.steps),
+                              _p(self.f), _p(self.g), _p(self.hbar), _p(self.fn), _p(self.gn), _p(self.h),
+                              _p(self.ref[0]), _p(self.ref[1]), _p(self.ref[2]), _p(rel))
 
     def _dims(self):
         return self.n
 
-    def refresh(self):
+    def refresh(self, rel_kind="relative"):
+        """densities -> noise -> hydrovars.  With a reference state the position handed to
+        thermal_noise depends on the caller: LBM_init -> COM relative to com_ref (:651-654),
+        LBM_init_mixture -> absolute COM (:623-625), LBM_init_stripe/_droplet -> zero (:690, :739)."""
         nx, ny, nz = self.n
+        if self.ref is not None:
+            if rel_kind == "zero":
+                rel = np.zeros(3)
+            else:
+                lib().orc_hydrovars_density(ctypes.byref(self.p), nx, ny, nz, _p(self.f), _p(self.g), _p(self.hbar))
+                rel = self.com() - (self.ref[3] if rel_kind == "relative" else 0.0)
+            return self._refresh_ref(rel)
         lib().orc_refresh(ctypes.byref(self.p), nx, ny, nz, ctypes.c_uint32(self.steps),
                           _p(self.f), _p(self.g), _p(self.hbar), _p(self.fn), _p(self.gn), _p(self.h))
 
@@ -103,19 +127,19 @@ class OracleLattice:
         nx, ny, nz = self.n
         lib().orc_init_mixture(ctypes.byref(self.p), nx, ny, nz, _p(self.f), _p(self.g))
         self.steps = 0
-        self.refresh()
+        self.refresh("absolute")
 
     def init_stripe(self, frac):
         nx, ny, nz = self.n
         lib().orc_init_stripe(ctypes.byref(self.p), nx, ny, nz, ctypes.c_double(frac), _p(self.f), _p(self.g))
         self.steps = 0
-        self.refresh()
+        self.refresh("zero")
 
     def init_droplet(self, r):
         nx, ny, nz = self.n
         lib().orc_init_droplet(ctypes.byref(self.p), nx, ny, nz, ctypes.c_double(r), _p(self.f), _p(self.g))
         self.steps = 0
-        self.refresh()
+        self.refresh("zero")
 
     def init_from(self, f0, g0):
         self.f[...] = f0
@@ -125,6 +149,13 @@ class OracleLattice:
 
     def timestep(self):
         nx, ny, nz = self.n
+        if self.ref is not None:
+            lib().orc_timestep_ref(ctypes.byref(self.p), nx, ny, nz, ctypes.c_uint32(self.steps),
+                                   _p(self.f), _p(self.g), _p(self._ft), _p(self._gt),
+                                   _p(self.hbar), _p(self.fn), _p(self.gn), _p(self.h),
+                                   _p(self.ref[0]), _p(self.ref[1]), _p(self.ref[2]), _p(self.ref[3]))
+            self.steps += 1
+            return
         lib().orc_timestep(ctypes.byref(self.p), nx, ny, nz, ctypes.c_uint32(self.steps),
                            _p(self.f), _p(self.g), _p(self._ft), _p(self._gt),
                            _p(self.hbar), _p(self.fn), _p(self.gn), _p(self.h))

@@ -108,3 +108,38 @@ def test_cpp_adapter_over_the_native_ring(nslabs):
     for args in [(12, 6, "droplet", 1e-5, 2.0), (12, 5, "stripe", 0, 1.5)]:
         assert _run_env({"BFLBM_NSLABS": str(nslabs)}, *args) == _run(*args)
     assert _run_env({"BFLBM_NSLABS": str(nslabs), "LBM_RESTART_CHECK": "1"}, 12, 6, "droplet", 0, 2.0) == _run(12, 6, "droplet", 0, 2.0)
+
+
+@pytest.mark.parametrize("nslabs", [1, 2])
+def test_cpp_driver_built_with_USE_REF_STATE(pkg, nslabs):
+    """cpp/lbm_run_job_ref = the same driver compiled with -DUSE_REF_STATE (the reference's switch,
+    LBM_binary.H:12): equilibrium fields from the initial state, com_ref from update_com(rho_eq) moved by
+    (2.6,-1.4,3.3), continuation through LBM_init, 5 noisy steps.  The python twin does the same calls."""
+    exe = EXE + "_ref"
+    n, steps, kbt, a0 = 12, 5, 1e-5, 2.0
+    r = subprocess.run([exe, str(n), str(steps), "droplet", str(kbt), str(a0)], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, BFLBM_NSLABS=str(nslabs)))
+    assert r.returncode == 0, r.stderr
+    o = {}
+    for line in r.stdout.splitlines():
+        k, _, v = line.partition(" ")
+        o[k] = v.split()
+    lbm = pkg.BinaryLBM(n, n, n, params=pkg.default_params(kBT=kbt, alpha0=a0))
+    lbm.LBM_init_droplet(0.2)
+    h = lbm.LBM_hydrovars()
+    f, g = lbm.populations()
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    com = np.array([(h[0] * x).sum(), (h[0] * y).sum(), (h[0] * z).sum()]) / h[0].sum()
+    lbm.set_ref_state(h[0], h[1], h[5], com - np.array([2.6, -1.4, 3.3]))
+    lbm.LBM_init(f, g)
+    lbm.LBM_timestep(steps)
+    f, g = lbm.populations()
+    fn, gn = lbm.thermal_noise()
+    hb = lbm.LBM_hydrovars_density()
+    assert float(o["fold(1,1,1,3)"][0]) == f[3, 1, 1, 1] and float(o["fold(1,1,1,3)"][2]) == g[7, 1, 1, 1]
+    assert float(o["fnoise(1,2,3,4)"][0]) == fn[4, 3, 2, 1] and float(o["fnoise(1,2,3,4)"][2]) == gn[18, 1, 2, 3]
+    assert float(o["rho(0,0,4)"][0]) == hb[0, 4, 0, 0]
+    # and the switch matters: the plain build draws different noise from the same seed
+    plain = _run(n, steps, "droplet", kbt, a0)
+    assert plain["fnoise(1,2,3,4)"] != o["fnoise(1,2,3,4)"]
+    lbm.close()

@@ -208,3 +208,35 @@ def test_rng_stream_properties(ob):
     assert [hex(v) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
     ob.lib().orc_philox(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, out)
     assert [hex(v) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+def test_ref_state_branch_of_the_oracle(ob):
+    """USE_REF_STATE restatement (LBM_binary.H:92-107): with the current densities as the reference state
+    and a zero shift it reproduces the shipped branch bit for bit; a shift of (sx,sy,sz) reads the
+    reference fields at x - s (one periodic wrap), and the amplitude of mode 4 scales with sqrt(rho_eq)."""
+    n = (8, 6, 10)
+    par = dict(kBT=1e-5, alpha0=2.0)
+    a = ob.OracleLattice(*n, ob.default_params(**par))
+    a.init_droplet(0.3)
+    b = ob.OracleLattice(*n, ob.default_params(**par))
+    b.set_ref_state(a.hbar[0], a.hbar[1], a.hbar[0] + a.hbar[1], a.com())
+    b.init_droplet(0.3)
+    assert np.array_equal(a.fn, b.fn) and np.array_equal(a.gn, b.gn) and np.array_equal(a.h, b.h)
+    # shifted lookup: relative COM (2.6,-1.4,3.3) -> shift (2,-1,3)
+    rng = np.random.default_rng(0)
+    rho_eq = 0.5 + rng.random(a.hbar[0].shape)
+    c = ob.OracleLattice(*n, ob.default_params(**par))
+    c.set_ref_state(rho_eq, rho_eq, 2 * rho_eq, a.com() - np.array([2.6, -1.4, 3.3]))
+    c.init_from(a.f, a.g)                                   # LBM_init: relative COM
+    shifted = np.roll(rho_eq, shift=(3, -1, 2), axis=(0, 1, 2))   # value at (x,y,z) = rho_eq(x-2, y+1, z-3)
+    d = ob.OracleLattice(*n, ob.default_params(**par))
+    d.set_ref_state(shifted, shifted, 2 * shifted, a.com())  # same fields pre-shifted, zero shift
+    d.init_from(a.f, a.g)
+    assert np.array_equal(c.fn, d.fn) and np.array_equal(c.gn, d.gn)
+    m = a.hbar[0] > 1e-3
+    np.testing.assert_allclose((c.fn[4] / np.sqrt(shifted))[m], (a.fn[4] / np.sqrt(a.hbar[0]))[m], rtol=1e-12)
+    # steps run and keep the mass (noise modes 0 are zero)
+    m0 = c.hbar[0].sum()
+    for _ in range(3):
+        c.timestep()
+    assert abs(c.hbar[0].sum() - m0) < 1e-10
