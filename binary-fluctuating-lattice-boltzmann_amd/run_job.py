@@ -17,6 +17,9 @@ What it mirrors (main_run_job.cpp line numbers):
 Frames hold `hydrovs` (22 components, VariableNames) -- the reference's STRUCT_HYDROVARS variant; with
 --lb-hydrovars the 15-component `hydrovsbar` is written under the same names like the shipped
 STRUCT_LB_HYDROVARS build does (main_run_job.cpp:19, :321).
+  * --use-ref-state: the noiseSwitch branch :216-235 for a build with USE_REF_STATE (LBM_binary.H:12) -- load the
+    three equilibrium files written by a previous kBT = 0 run, com_ref = update_com(rho_eq), and let
+    thermal_noise take its amplitudes from them
   * structure factors :99-103, :301-310, :342-349: accumulated every out_SF_step steps inside the last
     plot_SF_window steps of a noisy run and written with the last frame (structfact.py; shipped window = 0)
 """
@@ -94,6 +97,7 @@ def main(argv=None):
     ap.add_argument("--rho-lo", type=float, default=0.0)
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--max-grid-size", type=int, default=0, help="boxes per frame file; default nx/2 (:73)")
+    ap.add_argument("--use-ref-state", action="store_true", help="noise amplitudes from the equilibrium_* files (USE_REF_STATE)")
     ap.add_argument("--lb-hydrovars", action="store_true", help="write hydrovsbar (15 comps) like STRUCT_LB_HYDROVARS")
     ap.add_argument("--root", default=".")
     ap.add_argument("--device", type=int, default=0)
@@ -128,6 +132,16 @@ def main(argv=None):
     def write_output(step):                                                # WriteOutput :35-55
         pf.write_plotfile(pf.concatenate(paths["plot_root"], step, NDIGITS), frame(), names,
                           time=float(step), step=step, max_grid_size=mgs)
+
+    if noise and a.use_ref_state:                                          # :216-235
+        print("Noise switch on")
+        eq = [pf.read_plotfile(paths["eq"][k])[0][0] for k in ("rho", "phi", "rhot")]
+        z, y, x = np.meshgrid(np.arange(n[2]), np.arange(n[1]), np.arange(n[0]), indexing="ij")
+        m = eq[0].sum()
+        com_ref = np.array([(eq[0] * x).sum(), (eq[0] * y).sum(), (eq[0] * z).sum()]) / m     # update_com(rho_eq), :230
+        print("Mass rho_eq = %.17g" % m)
+        print("Center of Mass: (%g,%g,%g)" % tuple(com_ref))
+        lbm.set_ref_state(eq[0], eq[1], eq[2], com_ref)
 
     if a.restart:                                                          # :253-270
         chk_temp = 0.0 if a.continue_from_nonfluct else a.kbt

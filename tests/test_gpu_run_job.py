@@ -89,3 +89,24 @@ def test_noisy_job_structure_factor_window(pkg, tmp_path):
     k = hdr["names"].index("struct_fact_ufbarx_ufbarx")
     assert abs(mag[k].sum() / (16 ** 3 - 1) / kbt - 1.0) < 0.08, mag[k].sum() / (16 ** 3 - 1) / kbt
     assert os.path.isdir(os.path.join(run, "plt_SF_real_imag000001500"))
+
+
+def test_noisy_continuation_on_the_equilibrium_reference_state(pkg, tmp_path):
+    """ReadMe workflow B: relax a droplet at kBT = 0 (writes equilibrium_{rho,phi,rhot}_* and the last-frame
+    checkpoints), then continue from that frame with noise whose amplitudes come from the equilibrium
+    state (--use-ref-state = a USE_REF_STATE build, main_run_job.cpp:216-235, :253-270)."""
+    pf = pkg.plotfile
+    root = str(tmp_path / "R")
+    common = ["--system", "droplet", "--nx", "16", "--alpha0", "2.0", "--radius", "0.3", "--print-int", "0", "--root", root]
+    assert pkg.run_job.main(common + ["--nsteps", "40", "--plot-int", "10"]) == 0
+    d = os.path.join(root, "data_droplet_density_1.00_alpha0_2.00_r0.300_size16-16-16")
+    noisy = common + ["--kbt", "1e-6", "--nsteps", "20", "--plot-int", "20", "--restart", "--step-continue", "40"]
+    assert pkg.run_job.main(noisy + ["--use-ref-state"]) == 0
+    f_ref, _ = pf.read_plotfile(os.path.join(d, "f_checkpoint0000060_alpha0_2.00_xi_1.0e-06_size16-16-16"))
+    assert pkg.run_job.main(noisy) == 0
+    f_cur, _ = pf.read_plotfile(os.path.join(d, "f_checkpoint0000060_alpha0_2.00_xi_1.0e-06_size16-16-16"))
+    assert np.all(np.isfinite(f_ref)) and not np.array_equal(f_ref, f_cur)
+    # same random stream, slightly different amplitudes: the two runs stay close, and both keep the mass
+    assert np.abs(f_ref - f_cur).max() < 1e-3
+    f40, _ = pf.read_plotfile(os.path.join(d, "f_checkpoint0000040_alpha0_2.00_xi_0.0e+00_size16-16-16"))
+    assert abs(f_ref.sum() - f40.sum()) < 1e-9 and abs(f_cur.sum() - f40.sum()) < 1e-9
