@@ -142,30 +142,70 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
   double nb[Q], grad_rho[3], grad_phi[3];
   gather_field(rho, I, nb); d_gradient(P, nb, grad_rho);
   gather_field(phi, I, nb); d_gradient(P, nb, grad_phi);
-  double fn[Q], gn[Q];
+  // noise: the momentum modes first (the projection needs them), each fluid's other modes right before
+  // its relaxation; every fluid is stored as soon as it is collided -- keeps the live set small
+  const long long nvol = (long long)(G.nzs - 2*G.H)*G.plane;          // injected arrays: [a][p-H][y][x]
+  const long long no = (long long)(p - G.H)*G.plane + (long long)y*G.nx + x;
+  double fn3[3] = {0., 0., 0.}, gn3[3] = {0., 0., 0.};
+  NoiseAmp NA; float n3 = 0.f; uint64_t site = 0;
   if (INJECT) {
-    // injected arrays are dense over the slab's own planes: [a][p-H][y][x]
-    const long long nvol = (long long)(G.nzs - 2*G.H)*G.plane;
-    const long long no = (long long)(p - G.H)*G.plane + (long long)y*G.nx + x;
 #pragma unroll
-    for (int a = 0; a < Q; ++a) { fn[a] = injf[a*nvol + no]; gn[a] = injg[a*nvol + no]; }
+    for (int k = 0; k < 3; ++k) { fn3[k] = injf[(1 + k)*nvol + no]; gn3[k] = injg[(1 + k)*nvol + no]; }
   } else if (NOISE) {
     double ar, ap, at;
     noise_state(Rf, G, x, y, p, r, ph, ar, ap, at);
-    d_noise(P, ar, ap, at, global_site(G, x, y, p), noise_index, fn, gn);
-  } else {
+    site = global_site(G, x, y, p);
+    d_noise_amp(P, ar, ap, at, NA);
+    d_noise_head(P, NA, site, noise_index, fn3, n3);
 #pragma unroll
-    for (int a = 0; a < Q; ++a) { fn[a] = 0.; gn[a] = 0.; }
+    for (int k = 0; k < 3; ++k) gn3[k] = -fn3[k];
   }
   SiteHydro Hy;
   SiteRecip R;
   d_site_recips(P, r, ph, R);
-  d_hydrovars(P, fs, gs, r, ph, grad_rho, grad_phi, fn, gn, Hy, R);
-  d_collide<NOISE || INJECT>(P, fs, gs, r, ph, Hy, fn, gn, R);
+  {
+    double jf[3], jg[3];
+    d_momentum(fs, jf);
+    d_momentum(gs, jg);
+    d_hydrovars_j(P, jf, jg, r, ph, grad_rho, grad_phi, fn3, gn3, Hy, R);
+  }
+  double v_b[3];
+  d_barycentric(r, ph, Hy, v_b, R);
+  {
+    double fn[Q];
+    if (INJECT) {
 #pragma unroll
-  for (int i = 0; i < Q; ++i) {
-    D[(long long)i*G.vol + o] = fs[i];
-    D[(long long)(i+Q)*G.vol + o] = gs[i];
+      for (int a = 0; a < Q; ++a) fn[a] = injf[a*nvol + no];
+    } else if (NOISE) {
+      d_noise_f(P, NA, site, noise_index, fn3, n3, fn);
+    } else {
+#pragma unroll
+      for (int a = 0; a < Q; ++a) fn[a] = 0.;
+    }
+    double m[Q];
+    d_moments(fs, m);
+    d_relax<NOISE || INJECT>(P, m, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn, R.cs4);
+    d_populations(m, fs);
+#pragma unroll
+    for (int i = 0; i < Q; ++i) D[(long long)i*G.vol + o] = fs[i];
+  }
+  {
+    double gn[Q];
+    if (INJECT) {
+#pragma unroll
+      for (int a = 0; a < Q; ++a) gn[a] = injg[a*nvol + no];
+    } else if (NOISE) {
+      d_noise_g(P, NA, site, noise_index, fn3, gn);
+    } else {
+#pragma unroll
+      for (int a = 0; a < Q; ++a) gn[a] = 0.;
+    }
+    double m[Q];
+    d_moments(gs, m);
+    d_relax<NOISE || INJECT>(P, m, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn, R.cs4);
+    d_populations(m, gs);
+#pragma unroll
+    for (int i = 0; i < Q; ++i) D[(long long)(i+Q)*G.vol + o] = gs[i];
   }
 }
 

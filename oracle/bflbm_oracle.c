@@ -38,6 +38,12 @@
 #define NHBAR 15   /* hydrovsbar comps allocated by the driver (main_run_job.cpp:210); 0..8 written */
 #define NHYDRO 22  /* hydrovs comps (main_run_job.cpp:147) */
 
+/* Threads over z planes for the optional "all cores" timing of bench.py's cpu_baseline leg.  Sites are
+ * independent in every loop that carries the pragma, so results do not depend on the thread count;
+ * the default is 1 = the reference as shipped (serial build, GNUmakefile:16-19). */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+
 typedef struct orc_params {
   double tau_f, tau_g;   /* LBM_binary.H:18-19 */
   double alpha0, alpha1; /* LBM_binary.H:20-21 */
@@ -332,6 +338,7 @@ static void thermal_noise_impl(const orc_params* p, int nx, int ny, int nz, int 
   const double tau_f_bar2 = tau_f_bar*tau_f_bar;
   const double tau_g_bar2 = tau_g_bar*tau_g_bar;
   const double kBT = p->kBT, cs2 = p->cs2;
+  #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
     int gz = (z + gz0) % gnz; if (gz < 0) gz += gnz;
     double rho, phi, rhot;
@@ -412,6 +419,7 @@ static void gradient(const orc_params* p, int nx, int ny, int nz, int x, int y, 
 void orc_hydrovars_density(const orc_params* p, int nx, int ny, int nz,
                            const double* f, const double* g, double* hb) {
   (void)p;
+  #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
     double rho = 0.0, phi = 0.0;
     double fs[Q], gs[Q], mf[Q], mg[Q];
@@ -440,6 +448,7 @@ void orc_hydrovars(const orc_params* p, int nx, int ny, int nz,
                    const double* f, const double* g, const double* hbar,
                    const double* nf, const double* ng, double* h) {
   const double cs2 = p->cs2, alpha0 = p->alpha0, tau_f = p->tau_f, tau_g = p->tau_g;
+  #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
     double ufbar[3], ugbar[3], afbar[3], agbar[3];
     const double rho = hbar[IDX(nx,ny,nz,0,x,y,z)];
@@ -548,6 +557,7 @@ void orc_collide(const orc_params* p, int nx, int ny, int nz,
                  const double* fn, const double* gn) {
   const double tau_f_bar = p->tau_f*(1.+0.5/p->tau_f);
   const double tau_g_bar = p->tau_g*(1.+0.5/p->tau_g);
+  #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
     const double fields[2] = { h[IDX(nx,ny,nz,0,x,y,z)], h[IDX(nx,ny,nz,1,x,y,z)] };
     double uf[3], ug[3], af[3], ag[3], v_b[3];
@@ -582,6 +592,7 @@ void orc_collide(const orc_params* p, int nx, int ny, int nz,
 void orc_stream_push(int nx, int ny, int nz, const double* fold, const double* gold,
                      double* fnew, double* gnew) {
   for (int i = 0; i < Q; ++i)
+    #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
       int xp = wrap(x + C[i][0], nx), yp = wrap(y + C[i][1], ny), zp = wrap(z + C[i][2], nz);
       fnew[IDX(nx,ny,nz,i,xp,yp,zp)] = fold[IDX(nx,ny,nz,i,x,y,z)];

@@ -240,3 +240,19 @@ def test_ref_state_branch_of_the_oracle(ob):
     for _ in range(3):
         c.timestep()
     assert abs(c.hbar[0].sum() - m0) < 1e-10
+
+
+def test_threaded_oracle_is_bit_identical(ob):
+    """bench.py's 'all_cores' leg threads the oracle over z planes; sites are independent, so the result
+    must not depend on the thread count (noise included: the stream is counter-based)."""
+    outs = []
+    for nt in (1, 3):
+        ob.lib().orc_set_threads(nt)
+        a = ob.OracleLattice(10, 7, 9, ob.default_params(kBT=1e-5, alpha0=2.0))
+        a.init_droplet(0.3)
+        for _ in range(5):
+            a.timestep()
+        outs.append((a.f.copy(), a.g.copy(), a.h.copy(), a.fn.copy()))
+    ob.lib().orc_set_threads(1)
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
