@@ -8,6 +8,9 @@
 // With plot_root the final hydrovs frame, the noise and the f/g checkpoints are written as AMReX
 // plotfiles named like the reference's (main_run_job.cpp:42, :400-409; Debug.H:390-408).
 //
+// LBM_SF_WINDOW=w [LBM_SF_STEP=s]: structure factors like main_run_job.cpp:301-310, :342-349, :50-54 --
+// FortStructure(hydrovs, 0) every s steps inside the last w steps, WritePlotFile with the last frame.
+//
 // Built a second time with -DUSE_REF_STATE (lbm_run_job_ref), like the reference's compile-time switch
 // (LBM_binary.H:12): the run then mirrors the noiseSwitch flow of main_run_job.cpp:216-235, :253-270 --
 // equilibrium fields into rho_eq/phi_eq/rhot_eq (here: the initial state's hydrovs 0, 1, 5 instead of
@@ -27,6 +30,8 @@ using namespace bflbm::host;
 // #define USE_REF_STATE  -- from the command line (-DUSE_REF_STATE), before the adapter like before LBM_binary.H
 #include "../../include/bflbm_amrex.H"
 #include "../../include/bflbm_plotfile.H"
+#include "../../include/bflbm_structfact.H"
+using StructFact = bflbm::StructFact;                       // FHDeX's class in the reference's driver
 
 int main(int argc, char* argv[]) {
   if (argc < 4) { std::fprintf(stderr, "usage: %s nx [ny nz] nsteps system [kBT] [alpha0] [sync]\n", argv[0]); return 2; }
@@ -88,9 +93,25 @@ int main(int argc, char* argv[]) {
   }
 #endif
 
+  // set up StructFact (:299-310)
+  const std::vector<int> pairA = { 0,  1,  0,  2,  3,  4,  6,  7,  8,  2,  9,  15, 16, 17, 15, 18, 19, 20, 21, 20, 20, 21};
+  const std::vector<int> pairB = { 0,  1,  1,  2,  3,  4,  6,  7,  8,  6,  9,  15, 16, 17, 16, 18, 19, 20, 21, 21, 18, 18};
+  const std::vector<double> var_scaling(22, 1.0);
+  const std::vector<std::string> var_names = bflbm::VariableNames(nhydro);
+  const int dm = 0;                                         // no DistributionMapping in a single process
+  StructFact structFact(ba, dm, var_names, var_scaling, pairA, pairB);
+  const int plot_SF_window = std::getenv("LBM_SF_WINDOW") ? std::atoi(std::getenv("LBM_SF_WINDOW")) : 0;   // :99
+  const int out_SF_step = std::getenv("LBM_SF_STEP") ? std::atoi(std::getenv("LBM_SF_STEP")) : 100;        // :100
+  const int SF_start = nsteps - plot_SF_window;             // :330
+
   for (int step = 1; step <= nsteps; ++step) {              // :335-339
     if (legacy) LBM_timestep(geom, fold, gold, fnew, gnew, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq);
     else        LBM_timestep(geom, fold, gold, fnew, gnew, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq, com_ref);
+    if (plot_SF_window > 0 && step >= SF_start && step % out_SF_step == 0) structFact.FortStructure(hydrovs, 0);   // :342-349
+  }
+  if (plot_SF_window > 0 && !plot_root.empty()) {
+    structFact.WritePlotFile(nsteps, (double)nsteps, plot_root + "/plt_SF", 1);                           // :50-54
+    std::printf("sf_samples %lld\n", structFact.nsamples());
   }
   // restart path of the live driver (:253-270): continue from the populations just produced
   if (std::getenv("LBM_RESTART_CHECK") && std::atoi(std::getenv("LBM_RESTART_CHECK")) != 0) {

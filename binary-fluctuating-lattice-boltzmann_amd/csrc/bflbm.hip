@@ -1022,3 +1022,5 @@ int bflbm_ring_sync(bflbm_ring* r) {
 }
 
 }  // extern "C"
+
+#include "bflbm_sf.h"

@@ -96,8 +96,9 @@ def write_plotfile(name, data, names, time=0.0, step=0, max_grid_size=None,
             maxs.append(flat.max(axis=1))
     c = ["1", "0", str(ncomp), "0", f"({len(boxes)} 0"] + [_box_str(lo, hi) for lo, hi in boxes] + [")", str(len(boxes))]
     c += [f"FabOnDisk: Cell_D_00000 {o}" for o in offsets]
-    c += ["", f"{len(boxes)},{ncomp}"] + [",".join(_real(v) for v in m) + "," for m in mins]
-    c += ["", f"{len(boxes)},{ncomp}"] + [",".join(_real(v) for v in m) + "," for m in maxs]
+    # + 0.0: a minimum of -0.0 prints as 0 (min/max of mixed signed zeros is implementation-defined)
+    c += ["", f"{len(boxes)},{ncomp}"] + [",".join(_real(v + 0.0) for v in m) + "," for m in mins]
+    c += ["", f"{len(boxes)},{ncomp}"] + [",".join(_real(v + 0.0) for v in m) + "," for m in maxs]
     with open(os.path.join(name, "Level_0", "Cell_H"), "w") as fh:
         fh.write("\n".join(c) + "\n")
     return name

@@ -98,6 +98,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--max-grid-size", type=int, default=0, help="boxes per frame file; default nx/2 (:73)")
     ap.add_argument("--use-ref-state", action="store_true", help="noise amplitudes from the equilibrium_* files (USE_REF_STATE)")
+    ap.add_argument("--sf-device", action="store_true", help="accumulate the structure factors on the GPU (hipFFT)")
     ap.add_argument("--lb-hydrovars", action="store_true", help="write hydrovsbar (15 comps) like STRUCT_LB_HYDROVARS")
     ap.add_argument("--root", default=".")
     ap.add_argument("--device", type=int, default=0)
@@ -169,7 +170,9 @@ def main(argv=None):
 
     last = a.step_continue + a.nsteps
     plot_sf = a.plot_sf_window if noise else 0                              # :102
-    sf = pkg.structfact.StructFact(names) if plot_sf > 0 else None          # :310
+    sf = None                                                               # :310
+    if plot_sf > 0:
+        sf = pkg.structfact.DeviceStructFact(lbm, names) if a.sf_device else pkg.structfact.StructFact(names)
     sf_start = last - a.plot_sf_window                                      # :330
     out_step = a.step_continue + 2 * a.nsteps // 10 if noise else a.step_continue    # :89
     for step in range(a.step_continue + 1, last + 1):                       # :335-387
@@ -177,7 +180,7 @@ def main(argv=None):
         if a.print_int and step % a.print_int == 0 and step % (a.print_int * 50) == 0:
             print("LB step %d" % step)
         if sf is not None and step >= sf_start and step % a.out_sf_step == 0:   # :342-349
-            sf.fort_structure(frame(), 0)
+            sf.fort_structure(None if a.sf_device else frame(), 0)
         if noise and a.out_noise_step and step % a.out_noise_step == 0:     # WriteOutNoise, Debug.H:380-409
             fn, gn = lbm.thermal_noise()
             base = paths["plot_root"][:-3]

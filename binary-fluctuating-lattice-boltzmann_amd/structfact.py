@@ -10,8 +10,8 @@ sites and from what the notebook consumes -- "parity unpinned" for anything beyo
   * k = 0 at cell n/2 (fftshift), domain [-n/2 - 1/2, n/2 - 1/2] (the notebook's domain_left/right_edge);
   * normalisation: S(k) = a^(k) conj(b^(k)) / N with un-normalised FFTs, so that S_rho ~ rho kBT/cs2;
   * zero_avg != 0 removes the k = 0 mode.
-Host-side (numpy FFT of downloaded fields), like the reference's own host-gathered FFT (SURVEY 8f rank 2
-lists a rocFFT version as "next").
+`StructFact` is host-side (numpy FFT of downloaded fields); `DeviceStructFact` is the same accumulator on
+the GPU (hipFFT D2Z on the resident state, csrc/bflbm_sf.h) with the same interface and file output.
 """
 import numpy as np
 
@@ -55,14 +55,73 @@ class StructFact:
             s[:, 0, 0, 0] = 0.0
         return np.fft.fftshift(s, axes=(1, 2, 3))
 
-    def write_plotfile(self, step, time, root, zero_avg=1, max_grid_size=None):
+    def _parts(self, zero_avg):
         s = self.mean(zero_avg)
-        nz, ny, nx = s.shape[1:]
+        return np.abs(s), s.real, s.imag
+
+    def write_plotfile(self, step, time, root, zero_avg=1, max_grid_size=None):
+        mag, re, im = self._parts(zero_avg)
+        nz, ny, nx = mag.shape[1:]
         lo = (-nx / 2 - 0.5, -ny / 2 - 0.5, -nz / 2 - 0.5)
         hi = (nx / 2 - 0.5, ny / 2 - 0.5, nz / 2 - 0.5)
         names = self.pair_names()
-        pf.write_plotfile(pf.concatenate(root + "_mag", step, 9), np.abs(s), names, time, step, max_grid_size, lo, hi)
-        ri = np.concatenate([s.real, s.imag])
+        pf.write_plotfile(pf.concatenate(root + "_mag", step, 9), mag, names, time, step, max_grid_size, lo, hi)
+        ri = np.concatenate([re, im])
         pf.write_plotfile(pf.concatenate(root + "_real_imag", step, 9), ri,
                           [n + "_real" for n in names] + [n + "_imag" for n in names], time, step, max_grid_size, lo, hi)
-        return s
+        return re + 1j * im
+
+
+class DeviceStructFact(StructFact):
+    """The accumulator on the device: no field leaves the GPU until the mean is written.
+    `lbm` is a single-context BinaryLBM; frames are taken from its resident state."""
+
+    def __init__(self, lbm, var_names, pair_a=PAIR_A, pair_b=PAIR_B, var_scaling=None, lb_hydrovars=False):
+        import ctypes
+        from . import _lib
+        super().__init__(var_names, pair_a, pair_b, var_scaling)
+        self.lbm, self.lb = lbm, bool(lb_hydrovars)
+        self._ct, self._check, self._libh = ctypes, _lib.check, lbm.lib
+        n = len(self.pairs)
+        a = (ctypes.c_int * n)(*[p[0] for p in self.pairs])
+        b = (ctypes.c_int * n)(*[p[1] for p in self.pairs])
+        sc = (ctypes.c_double * n)(*[float(v) for v in self.scale])
+        h = ctypes.c_void_p()
+        _lib.check(lbm.lib.bflbm_sf_create(lbm._h, n, a, b, sc, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._libh.bflbm_sf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        if getattr(self, "_h", None):
+            self._check(self._libh.bflbm_sf_reset(self._h))
+        self.nsamples = 0
+
+    def fort_structure(self, fields=None, reset=0):
+        """FortStructure on the resident state (`fields` is ignored: nothing is downloaded)."""
+        self._check(self._libh.bflbm_sf_accumulate(self._h, int(self.lb), int(bool(reset))))
+        self.nsamples = 1 if reset else self.nsamples + 1
+
+    def _get(self, what, zero_avg):
+        nx, ny, nz = self.lbm.n
+        out = np.empty((len(self.pairs), nz, ny, nx))
+        self._check(self._libh.bflbm_sf_get(self._h, what, int(bool(zero_avg)), out.ctypes.data_as(self._ct.c_void_p)))
+        return out
+
+    def mean(self, zero_avg=1):
+        return self._get(1, zero_avg) + 1j * self._get(2, zero_avg)
+
+    def _parts(self, zero_avg):
+        return self._get(0, zero_avg), self._get(1, zero_avg), self._get(2, zero_avg)
+
+    def magnitude(self, zero_avg=1):
+        return self._get(0, zero_avg)

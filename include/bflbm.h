@@ -212,6 +212,22 @@ int bflbm_set_com(bflbm_ctx* c, const double com[3]);
 
 int bflbm_sync(bflbm_ctx* c);
 
+/* ---- Structure factors on the device (FHDeX StructFact as the reference drives it: pair list
+ * main_run_job.cpp:301-310, FortStructure every out_SF_step steps :342-349, WritePlotFile :50-54).
+ * S_ab(k) = < a^(k) conj(b^(k)) > / N with un-normalised transforms (hipFFT D2Z), averaged over the
+ * accumulated frames.  var_a/var_b index hydrovs (VariableNames order) or, with lb_hydrovars != 0,
+ * hydrovsbar (the shipped STRUCT_LB_HYDROVARS build, main_run_job.cpp:19, :344); scale may be NULL (1).
+ * bflbm_sf_get returns the full fft-shifted spectrum (k = 0 at cell n/2) [npairs][nz][ny][nx]:
+ * what 0 magnitude, 1 real, 2 imaginary part; zero_avg != 0 removes k = 0.  Needs the whole lattice in
+ * one context (nranks == 1).  hipFFT is loaded at first use; without it these calls fail, nothing else. */
+typedef struct bflbm_sf bflbm_sf;
+int bflbm_sf_create(bflbm_ctx* c, int npairs, const int* var_a, const int* var_b, const double* scale, bflbm_sf** out);
+int bflbm_sf_destroy(bflbm_sf* s);
+int bflbm_sf_reset(bflbm_sf* s);
+int bflbm_sf_accumulate(bflbm_sf* s, int lb_hydrovars, int reset);
+int bflbm_sf_nsamples(const bflbm_sf* s, long long* n);
+int bflbm_sf_get(bflbm_sf* s, int what, int zero_avg, double* dst);
+
 /* hipEvent timing on the context's stream: start, run steps, stop -> milliseconds. */
 int bflbm_timer_start(bflbm_ctx* c);
 int bflbm_timer_stop(bflbm_ctx* c, float* ms);

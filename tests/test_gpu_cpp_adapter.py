@@ -143,3 +143,28 @@ def test_cpp_driver_built_with_USE_REF_STATE(pkg, nslabs):
     plain = _run(n, steps, "droplet", kbt, a0)
     assert plain["fnoise(1,2,3,4)"] != o["fnoise(1,2,3,4)"]
     lbm.close()
+
+
+def test_cpp_structfact_object_writes_the_python_files(pkg, tmp_path):
+    """bflbm::StructFact with FHDeX's three call shapes (main_run_job.cpp:310, :344, :53) in the C++ driver:
+    the _SF_mag / _SF_real_imag plotfiles are byte-identical to structfact.DeviceStructFact's."""
+    import filecmp
+    n, steps, kbt = 12, 40, 1e-5
+    out = tmp_path / "cpp"; out.mkdir()
+    r = subprocess.run([EXE, str(n), str(steps), "mixture", str(kbt), "0", "2", str(out)], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, LBM_SF_WINDOW="30", LBM_SF_STEP="10"))
+    assert r.returncode == 0, r.stderr
+    assert "sf_samples 4" in r.stdout                       # steps 10, 20, 30, 40
+    lbm = pkg.BinaryLBM(n, n, n, params=pkg.default_params(kBT=kbt, alpha0=0.0))
+    lbm.LBM_init_mixture()
+    sf = pkg.structfact.DeviceStructFact(lbm, pkg.plotfile.variable_names(22))
+    for step in range(1, steps + 1):
+        lbm.LBM_timestep(1)
+        if step >= steps - 30 and step % 10 == 0:
+            sf.fort_structure()
+    py = tmp_path / "py"; py.mkdir()
+    sf.write_plotfile(steps, float(steps), str(py / "plt_SF"), 1, max_grid_size=n // 2)
+    for name in ("plt_SF_mag%09d" % steps, "plt_SF_real_imag%09d" % steps):
+        for f in ("Header", "Level_0/Cell_H", "Level_0/Cell_D_00000"):
+            assert filecmp.cmp(out / name / f, py / name / f, shallow=False), (name, f)
+    sf.close(); lbm.close()
