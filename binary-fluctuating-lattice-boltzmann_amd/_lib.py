@@ -96,6 +96,10 @@ SIGNATURES = {
     "bflbm_com_sums": (ctypes.c_int, [_vp, _dp]),
     "bflbm_mass": (ctypes.c_int, [_vp, _dp, _dp]),
     "bflbm_sync": (ctypes.c_int, [_vp]),
+    "bflbm_droplet_moments": (ctypes.c_int, [_vp, _dp]),
+    "bflbm_ring_droplet_moments": (ctypes.c_int, [_vp, _dp]),
+    "bflbm_fit_droplet": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_double, _dp, _P(ctypes.c_int)]),
+    "bflbm_ring_fit_droplet": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_double, _dp, _P(ctypes.c_int)]),
     "bflbm_sf_create": (ctypes.c_int, [_vp, ctypes.c_int, _P(ctypes.c_int), _P(ctypes.c_int), _dp, _P(_vp)]),
     "bflbm_sf_destroy": (ctypes.c_int, [_vp]),
     "bflbm_sf_reset": (ctypes.c_int, [_vp]),

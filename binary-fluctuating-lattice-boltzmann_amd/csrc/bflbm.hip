@@ -1024,3 +1024,4 @@ int bflbm_ring_sync(bflbm_ring* r) {
 }  // extern "C"
 
 #include "bflbm_sf.h"
+#include "bflbm_droplet.h"

@@ -53,7 +53,35 @@ def _check_array(a, ncomp, shape3, name):
         raise ValueError(f"{name}: shape {a.shape}, expected {(ncomp,) + tuple(shape3)}")
 
 
-class BinaryLBM:
+class _DropletMixin:
+    """Droplet observables reduced on the device (csrc/bflbm_droplet.h); `_droplet_fn` names the C-ABI pair."""
+
+    def droplet_moments(self):
+        """20 raw mass moments of rho (see include/bflbm.h); feed analysis.*_from_moments."""
+        m = (ctypes.c_double * 20)()
+        check(getattr(self.lib, self._droplet_fn[0])(self._h, m))
+        return np.array(list(m))
+
+    def fit_droplet(self, r0=None, p0=None, max_iter=200, tol=1e-12):
+        """(hi, lo, R, W) of the tanh profile about r0 (default: the centre of mass), unit-box coordinates.
+        Start values default to the notebook's (max rho, min rho, 0.5, 0.5) with max/min replaced by the
+        model's natural bounds rho_hi, rho_lo of the parameters."""
+        from . import analysis
+        if r0 is None:
+            r0 = analysis.com_from_moments(self.droplet_moments(), self.n)
+        if p0 is None:
+            p0 = (float(self.params.rho_hi), float(self.params.rho_lo), 0.5, 0.5)
+        r = (ctypes.c_double * 3)(*[float(v) for v in r0])
+        p = (ctypes.c_double * 4)(*[float(v) for v in p0])
+        cost, it = ctypes.c_double(), ctypes.c_int()
+        check(getattr(self.lib, self._droplet_fn[1])(self._h, r, p, int(max_iter), float(tol), ctypes.byref(cost), ctypes.byref(it)))
+        self.last_fit = dict(cost=cost.value, iterations=it.value)
+        return tuple(p)
+
+
+class BinaryLBM(_DropletMixin):
+    _droplet_fn = ("bflbm_droplet_moments", "bflbm_fit_droplet")
+
     """One z-slab [z0, z1) of a periodic nx*ny*nz D3Q19 binary-fluid lattice on one GPU."""
 
     def __init__(self, nx, ny=None, nz=None, params=None, z0=0, z1=None, rank=0, nranks=1,
@@ -301,7 +329,9 @@ class BinaryLBM:
         return n.value
 
 
-class RingLBM:
+class RingLBM(_DropletMixin):
+    _droplet_fn = ("bflbm_ring_droplet_moments", "bflbm_ring_fit_droplet")
+
     """The whole lattice as a ring of z-slabs driven by this one process through the native ring of the
     C-ABI (bflbm_ring_*): slab r on GPU devices[r % len(devices)], halo exchange by peer copies overlapped
     with the interior planes.  Same operator surface as BinaryLBM; fields are full-lattice arrays."""

@@ -228,6 +228,21 @@ int bflbm_sf_accumulate(bflbm_sf* s, int lb_hydrovars, int reset);
 int bflbm_sf_nsamples(const bflbm_sf* s, long long* n);
 int bflbm_sf_get(bflbm_sf* s, int what, int zero_avg, double* dst);
 
+/* ---- Droplet observables reduced on the device (Droplet_Fluctuation.ipynb / Surface_Tension.ipynb
+ * cell 3; the reference's C++ twins getCenterOfMass / fittingDropletCovariance / fittingDropletParams,
+ * LBM_hydrovs.H:62-335, are off by default, main_run_job.cpp:111).
+ * moments[0..9]  = sum over the slab's cells of rho * {1, x, y, z, xx, xy, xz, yy, yz, zz}, x,y,z = GLOBAL
+ * cell indices; moments[10..19] = the same with trapezoid weights (the lattice's end planes count half in
+ * each direction: Integration::trapezoid3DWeightTensor, the notebook's wt).  Centre of mass, covariance
+ * and principal axes follow on the host from these 20 numbers (analysis.py: *_from_moments).
+ * bflbm_fit_droplet: least-squares fit of rho(r) = hi - (hi-lo)/2 (1 + tanh((r-R)/W)), r = distance of the
+ * cell centre (i+1/2)/n from r0 in the unit box (the notebook's model), by Levenberg-Marquardt on normal
+ * equations reduced on the device; params = (hi, lo, R, W) start values in, solution out. */
+int bflbm_droplet_moments(bflbm_ctx* c, double moments[20]);
+int bflbm_ring_droplet_moments(bflbm_ring* r, double moments[20]);
+int bflbm_fit_droplet(bflbm_ctx* c, const double r0[3], double params[4], int max_iter, double tol, double* cost, int* iterations);
+int bflbm_ring_fit_droplet(bflbm_ring* r, const double r0[3], double params[4], int max_iter, double tol, double* cost, int* iterations);
+
 /* hipEvent timing on the context's stream: start, run steps, stop -> milliseconds. */
 int bflbm_timer_start(bflbm_ctx* c);
 int bflbm_timer_stop(bflbm_ctx* c, float* ms);

@@ -1,0 +1,88 @@
+"""GPU: droplet observables reduced on the device (csrc/bflbm_droplet.h) against their host-side numpy
+twins (analysis.py, the notebooks' definitions).  The reference's own numbers for these observables
+(Droplet_Fluctuation.ipynb cell 5) are asserted in test_gpu_fullsize.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _relaxed(pkg, n, steps=300, **kw):
+    lbm = pkg.BinaryLBM(*n, params=pkg.default_params(alpha0=2.5), **kw)
+    lbm.LBM_init_droplet(0.25)
+    lbm.LBM_timestep(steps)
+    return lbm
+
+
+@pytest.mark.parametrize("n", [(24, 24, 24), (20, 28, 24)])
+def test_moments_com_covariance(pkg, n):
+    an = pkg.analysis
+    lbm = _relaxed(pkg, n)
+    rho = lbm.LBM_hydrovars(ncomp=1)[0]
+    rho_xyz = np.ascontiguousarray(rho.transpose(2, 1, 0))
+    m = lbm.droplet_moments()
+    assert m.shape == (20,)
+    np.testing.assert_allclose(m[0], rho.sum(), rtol=1e-13)
+    np.testing.assert_allclose(an.com_from_moments(m, n), an.centre_of_mass(rho_xyz), rtol=1e-12)
+    np.testing.assert_allclose((lbm.update_com() + 0.5) / np.array(n), an.com_from_moments(m, n), rtol=1e-13)
+    c_host = an.mass_covariance(rho_xyz)
+    c_dev = an.covariance_from_moments(m, n, "notebook")
+    np.testing.assert_allclose(c_dev, c_host, rtol=1e-9, atol=1e-12 * np.abs(c_host).max())
+    ev_h = np.sort(np.linalg.eigvalsh(c_host)); ev_d = np.sort(np.linalg.eigvalsh(c_dev))
+    np.testing.assert_allclose(ev_d, ev_h, rtol=1e-9)
+    # the reference's C++ definition (fittingDropletCovariance, LBM_hydrovs.H:262-335): plain sums about the
+    # trapezoid-weighted centre of mass, restated here on the host
+    x, y, z = [(np.arange(k) + 0.5) / k for k in n]
+    wt = np.ones(rho_xyz.shape)
+    for ax in range(3):
+        sl = [slice(None)] * 3
+        for end in (0, -1):
+            sl[ax] = end
+            wt[tuple(sl)] *= 0.5
+    w = rho_xyz * wt
+    comw = np.array([(w * x[:, None, None]).sum(), (w * y[None, :, None]).sum(), (w * z[None, None, :]).sum()]) / w.sum()
+    np.testing.assert_allclose(an.com_from_moments(m, n, weighted=True), comw, rtol=1e-12)
+    d = [x[:, None, None] - comw[0], y[None, :, None] - comw[1], z[None, None, :] - comw[2]]
+    cref = np.array([[(d[a] * d[b] * rho_xyz).sum() for b in range(3)] for a in range(3)]) / rho_xyz.sum()
+    np.testing.assert_allclose(an.covariance_from_moments(m, n, "reference"), cref, rtol=1e-9, atol=1e-12 * np.abs(cref).max())
+    lbm.close()
+
+
+def test_device_tanh_fit_matches_scipy(pkg):
+    """Same least-squares problem as analysis.fit_droplet (scipy curve_fit over all sites).  MINPACK stops
+    when the COST changes by < 1.5e-8 relative, which leaves the parameters of this shallow valley (a diffuse
+    droplet, W > R) uncertain at the 1e-5 level; the device solver iterates to a stationary point, so: the
+    parameters agree to 1e-4, the device cost is not larger, and the gradient vanishes there."""
+    an = pkg.analysis
+    n = (32, 32, 32)
+    lbm = _relaxed(pkg, n, 500)
+    rho_xyz = np.ascontiguousarray(lbm.LBM_hydrovars(ncomp=1)[0].transpose(2, 1, 0))
+    host = np.array(an.fit_droplet(rho_xyz))
+    dev = np.array(lbm.fit_droplet())
+    np.testing.assert_allclose(dev, host, rtol=1e-4, atol=1e-6)
+    assert lbm.last_fit["iterations"] < 100
+    # cost at the device optimum is not worse than at scipy's
+    rho, r = an.radial_profile(rho_xyz)
+    cost = lambda p: ((rho - (p[0] - (p[0] - p[1]) / 2 * (1 + np.tanh((r - p[2]) / p[3])))) ** 2).sum()
+    assert cost(dev) <= cost(host) * (1 + 1e-12)
+    np.testing.assert_allclose(lbm.last_fit["cost"], cost(dev), rtol=1e-9)
+    eps = 1e-6
+    grad = np.array([(cost(dev + eps * np.eye(4)[k]) - cost(dev - eps * np.eye(4)[k])) / (2 * eps) for k in range(4)])
+    grad_host = np.array([(cost(host + eps * np.eye(4)[k]) - cost(host - eps * np.eye(4)[k])) / (2 * eps) for k in range(4)])
+    assert np.abs(grad).max() <= max(np.abs(grad_host).max(), 1e-7), (grad, grad_host)
+    # explicit centre and start values
+    dev2 = np.array(lbm.fit_droplet(r0=an.centre_of_mass(rho_xyz), p0=(rho_xyz.max(), rho_xyz.min(), 0.5, 0.5)))
+    np.testing.assert_allclose(dev2, dev, rtol=1e-6, atol=1e-8)
+    lbm.close()
+
+
+@pytest.mark.parametrize("nslabs", [2, 3])
+def test_droplet_observables_on_a_decomposed_lattice(pkg, nslabs):
+    n = (24, 24, 24)
+    one = _relaxed(pkg, n, 100)
+    ring = pkg.RingLBM(*n, nslabs=nslabs, params=pkg.default_params(alpha0=2.5))
+    ring.LBM_init_droplet(0.25)
+    ring.LBM_timestep(100)
+    np.testing.assert_allclose(ring.droplet_moments(), one.droplet_moments(), rtol=1e-12)
+    np.testing.assert_allclose(ring.fit_droplet(), one.fit_droplet(), rtol=1e-9)
+    one.close(); ring.close()

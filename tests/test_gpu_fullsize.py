@@ -125,4 +125,12 @@ def test_droplet_notebook_centre_of_mass_after_20000_steps(pkg):
     axes, ev, _ = an.principal_axes(rho_xyz, R)
     assert np.allclose(np.sort(ev), np.sort([0.03491747, 0.03496081, 0.03491747]), rtol=0, atol=6e-9), ev
     assert np.allclose(np.sort(axes), np.sort([0.1668965, 0.16700005, 0.1668965]), rtol=0, atol=3e-7), axes
+    # ... and the same notebook numbers without any field leaving the GPU (csrc/bflbm_droplet.h)
+    mom = lbm.droplet_moments()
+    assert ["%.8f" % v for v in an.com_from_moments(mom, (n, n, n))] == ["0.50470332"] * 3
+    hi_d, lo_d, R_d, W_d = lbm.fit_droplet()
+    assert abs(R_d - 0.1669310108163054) < 2e-7, R_d
+    axes_d, ev_d, _ = an.principal_axes_from_moments(mom, (n, n, n), R_d)
+    assert np.allclose(np.sort(ev_d), np.sort([0.03491747, 0.03496081, 0.03491747]), rtol=0, atol=6e-9), ev_d
+    assert np.allclose(np.sort(axes_d), np.sort([0.1668965, 0.16700005, 0.1668965]), rtol=0, atol=3e-7), axes_d
     lbm.close()
