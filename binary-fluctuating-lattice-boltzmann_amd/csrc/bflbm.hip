@@ -155,10 +155,10 @@ int launch_collide(bflbm_ctx* c, int pa, int pb) {
   return 0;
 }
 
-int launch_fused(bflbm_ctx* c, int pa, int pb) {
+int launch_fused(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
   if (pb <= pa) return 0;
   return fused_launch(c->S[c->cur], c->S[1 - c->cur], c->injf, c->injg, c->G, c->dp, pa, pb,
-                      (uint32_t)c->steps, c->inject ? 2 : (c->dp.noise_on ? 1 : 0), c->stream) ? fail("fused launch failed: %s", hipGetErrorString(hipGetLastError())) : 0;
+                      (uint32_t)c->steps, c->inject ? 2 : (c->dp.noise_on ? 1 : 0), c->stream, pair_len) ? fail("fused launch failed: %s", hipGetErrorString(hipGetLastError())) : 0;
 }
 
 // auto: the fused kernel is the faster one at zero noise (one HBM pass); with thermal noise the step
@@ -508,6 +508,7 @@ int bflbm_step_boundary(bflbm_ctx* c) {
   const int lo = own_lo(c), hi = own_hi(c);
   if (c->G.zwrap) return 0;                      // single slab: everything is "interior"
   if (resolved_schedule(c) == 1) {
+    if (hi - lo > 4) return launch_fused(c, lo, hi, 2);      // both boundary plane pairs in one launch
     if (launch_fused(c, lo, lo + 2)) return 1;
     return launch_fused(c, hi - 2, hi);
   }

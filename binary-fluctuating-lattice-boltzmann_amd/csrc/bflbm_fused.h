@@ -27,6 +27,7 @@ struct FusedGrid {
   int ntx, nty;        // tiles in x and y
   int pa, pb;          // storage planes [pa,pb) to advance
   int lz;              // planes per chunk
+  int cstride;         // planes between the starts of consecutive chunks (== lz unless the chunks are disjoint)
   int nchunks;
   int ncols;           // ntx*nty
   int total;           // ncols*nchunks workgroups
@@ -116,7 +117,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   const int lhalo = hly * LW + hlx;
 
   // ---- chunk of planes
-  const int qa = F.pa + chunk * F.lz;
+  const int qa = F.pa + chunk * F.cstride;
   const int qb = min(F.pb, qa + F.lz);
   auto wrapp = [&](int q) {                      // q in [-2, nzs+1]; nzs may be 1, so use a true modulo
     if (!G.zwrap) return q;
@@ -293,7 +294,9 @@ static int g_stamp_n = 0;
 // returns non-zero on launch failure
 static inline int fused_launch(const double* S, double* D, const double* injf, const double* injg,
                                const Geo& G, const DevParams& P, int pa, int pb,
-                               uint32_t noise_index, int mode, hipStream_t stream) {
+                               uint32_t noise_index, int mode, hipStream_t stream, int pair_len = 0) {
+  // pair_len > 0: ONE launch over the two disjoint plane ranges [pa, pa+pair_len) and [pb-pair_len, pb)
+  // (the boundary plane pairs of a slab), one chunk each.
   constexpr int TX = BFLBM_FUSED_TX, TY = BFLBM_FUSED_TY;
   FusedGrid F;
   F.ntx = (G.nx + TX - 1) / TX;
@@ -318,6 +321,8 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   if (nchunks < 1) nchunks = 1;
   F.lz = (np + nchunks - 1) / nchunks;
   F.nchunks = (np + F.lz - 1) / F.lz;
+  F.cstride = F.lz;
+  if (pair_len > 0 && np > 2 * pair_len) { F.lz = pair_len; F.nchunks = 2; F.cstride = np - pair_len; }
   F.total = F.ncols * F.nchunks;
   F.per_xcd = (F.total + 7) / 8;
   F.dbg = nullptr;
