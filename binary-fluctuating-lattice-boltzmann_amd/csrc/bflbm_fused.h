@@ -72,9 +72,14 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   constexpr int LW = TX + 2;                     // LDS row length
   constexpr int LSZ = (TX + 2) * (TY + 2);
   constexpr int NW = TX * TY / 64;
-  static_assert(2 * (2 * (TX + 2) + 2 * TY) <= 64 * NW, "ring half-tasks must fit one per lane");
+  static_assert(NW % 2 == 0 && (2 * (TX + 2) + 2 * TY) <= 64 * (NW / 2), "ring tasks of one fluid must fit one per lane of half the waves");
   __shared__ double rp[4][2][LSZ];               // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
   __shared__ double gl[Q][TX * TY];              // g populations of the previous plane
+#ifdef BFLBM_NOISE_EARLY
+  // MODE 1: the 18 normals of fluid f (stream blocks 0..4) of the plane collided next, drawn while the
+  // loads of the current plane are in flight (pure VALU work under memory latency); thread-private columns
+  __shared__ float nl[MODE == 1 ? 18 : 1][MODE == 1 ? TX * TY : 1];
+#endif
 
   int col, chunk;
   if (!fused_map(F, (int)blockIdx.x, col, chunk)) return;   // whole workgroup leaves together
@@ -90,19 +95,24 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   const bool loader = (tx < aw) && (ty < ah);
   const bool interior = loader;
   const int x = loader ? x0 + tx : x0, y = loader ? y0 + ty : y0;
-  const unsigned xo[3] = { (unsigned)wrapx(x - 1), (unsigned)x, (unsigned)wrapx(x + 1) };
-  const unsigned yo[3] = { (unsigned)(wrapy(y - 1) * G.nx), (unsigned)(y * G.nx), (unsigned)(wrapy(y + 1) * G.nx) };
-  // ---- ring half-task of this thread: lanes 0..nper-1 of every wave
+  // byte offsets: a plane is < 4 GB (checked at creation), so  address = wave-uniform base + 32-bit lane
+  // offset  and the loads/stores use the scalar-base addressing form (no 64-bit per-lane address math)
+  const unsigned xo[3] = { (unsigned)wrapx(x - 1) * 8u, (unsigned)x * 8u, (unsigned)wrapx(x + 1) * 8u };
+  const unsigned yo[3] = { (unsigned)(wrapy(y - 1) * G.nx) * 8u, (unsigned)(y * G.nx) * 8u, (unsigned)(wrapy(y + 1) * G.nx) * 8u };
+  auto ld = [](const double* __restrict__ base, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff); };
+  auto st = [](double* __restrict__ base, unsigned boff, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v; };
+  // ---- ring half-task of this thread: lanes 0..nper-1 of every wave; the lower half of the waves sums
+  // fluid f, the upper half fluid g, so the fluid (and with it the load base) is wave-uniform
   const int nring = 2 * (aw + 2) + 2 * ah;
-  const int ntask = 2 * nring;
-  const int nper = (ntask + NW - 1) / NW;
-  const int lane = tid & 63, wv = tid >> 6;
-  const int task = wv * nper + lane;
-  const bool has_task = (BFLBM_ABL & 1) ? false : (lane < nper && task < ntask);
-  int hfl = 0, hlx = 0, hly = 0;                 // fluid, LDS coordinates of the ring site
+  const int nper = (nring + NW / 2 - 1) / (NW / 2);
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hfl = wv / (NW / 2);
+  const int task = (wv % (NW / 2)) * nper + lane;
+  const bool has_task = (BFLBM_ABL & 1) ? false : (lane < nper && task < nring);
+  int hlx = 0, hly = 0;                          // LDS coordinates of the ring site
   if (has_task) {
-    hfl = task / nring;
-    const int r = task - hfl * nring;
+    const int r = task;
     if (r < aw + 2) { hlx = r; hly = 0; }
     else if (r < 2 * (aw + 2)) { hlx = r - (aw + 2); hly = ah + 1; }
     else if (r < 2 * (aw + 2) + ah) { hlx = 0; hly = r - 2 * (aw + 2) + 1; }
@@ -110,8 +120,8 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   }
   const int hx = wrapx(x0 + hlx - 1);            // in [-1, nx]: one wrap suffices
   const int hy = wrapy(y0 + hly - 1);
-  const unsigned hxo[3] = { (unsigned)wrapx(hx - 1), (unsigned)hx, (unsigned)wrapx(hx + 1) };
-  const unsigned hyo[3] = { (unsigned)(wrapy(hy - 1) * G.nx), (unsigned)(hy * G.nx), (unsigned)(wrapy(hy + 1) * G.nx) };
+  const unsigned hxo[3] = { (unsigned)wrapx(hx - 1) * 8u, (unsigned)hx * 8u, (unsigned)wrapx(hx + 1) * 8u };
+  const unsigned hyo[3] = { (unsigned)(wrapy(hy - 1) * G.nx) * 8u, (unsigned)(hy * G.nx) * 8u, (unsigned)(wrapy(hy + 1) * G.nx) * 8u };
 
   const int lown = (ty + 1) * LW + (tx + 1);
   const int lhalo = hly * LW + hlx;
@@ -145,10 +155,17 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
     // 1. pull plane q: the halo row first, then the own site; everything is in flight together
     double hv[Q];
     if (has_task) {
+      // the nine (dy,dx) offsets as opaque 32-bit values INSIDE this block: instruction selection then sees
+      // base + zext(offset) and uses the scalar-base addressing form instead of 64-bit per-lane adds
+      unsigned ho[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) { ho[a][b2] = hyo[a] + hxo[b2]; asm volatile("" : "+v"(ho[a][b2])); }
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
         const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)hfl * Q * G.vol + (long long)i * G.vol;
-        hv[i] = b[hyo[1 - Vel::cy[i]] + hxo[1 - Vel::cx[i]]];
+        hv[i] = ld(b, ho[1 - Vel::cy[i]][1 - Vel::cx[i]]);
       }
     } else {
 #pragma unroll
@@ -156,21 +173,47 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
     }
     double cf[Q], cg[Q];
     if (loader) {
+      unsigned oo[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) { oo[a][b2] = yo[a] + xo[b2]; asm volatile("" : "+v"(oo[a][b2])); }
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
         const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
-        const unsigned o = yo[1 - Vel::cy[i]] + xo[1 - Vel::cx[i]];
-        cf[i] = b[o];
-        cg[i] = b[(long long)Q * G.vol + o];
+        const unsigned o = oo[1 - Vel::cy[i]][1 - Vel::cx[i]];
+        cf[i] = ld(b, o);
+        cg[i] = ld(b + (long long)Q * G.vol, o);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < Q; ++i) { cf[i] = 0.; cg[i] = 0.; }
     }
     STAMP(0);                                   // loads issued
-    // 2. densities of plane q into the ring slot
-    if (has_task) rp[slot][hfl][lhalo] = d_density(hv);
-    if (loader) { rp[slot][0][lown] = d_density(cf); rp[slot][1][lown] = d_density(cg); }
+#ifdef BFLBM_NOISE_EARLY
+    if (MODE == 1) {
+      if ((q - 1 >= qa) && (q - 1 < qb) && interior) {
+        const uint64_t site_prev = global_site(G, x, y, wrapp(q - 1));
+        float nr[20];
+#pragma unroll
+        for (uint32_t blk = 0; blk < 5; ++blk)
+          bflbm_rng_block(P.seed_lo, P.seed_hi, site_prev, noise_index, blk, nr[4*blk], nr[4*blk+1], nr[4*blk+2], nr[4*blk+3]);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) nl[k][tid] = nr[k];
+      }
+    }
+#endif
+    // 2. densities of plane q into the ring slot.  The sums start from an opaque zero defined HERE: with a
+    // literal 0.0 the compiler sinks the first addition (0.0 + f_0) into the load blocks above and waits
+    // for the first load before it issues the rest.
+    double zero = 0.0;
+    asm volatile("" : "+v"(zero));
+    auto density = [&](const double (&fs)[Q]) { double r = zero;
+#pragma unroll
+      for (int i = 0; i < Q; ++i) r += fs[i];
+      return r; };
+    if (has_task) rp[slot][hfl][lhalo] = density(hv);
+    if (loader) { rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg); }
     STAMP(1);                                   // data arrived, sums done
     __syncthreads();
     STAMP(2);                                   // barrier
@@ -211,19 +254,25 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
         nb_g = injg + (long long)(pc - G.H) * G.plane;
         no = yo[1] + xo[1];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { fn3[k] = nb_f[(1 + k) * nvol + no]; gn3[k] = nb_g[(1 + k) * nvol + no]; }
+        for (int k = 0; k < 3; ++k) { fn3[k] = ld(nb_f + (1 + k) * nvol, no); gn3[k] = ld(nb_g + (1 + k) * nvol, no); }
       } else if (MODE == 1) {
         site = global_site(G, x, y, pc);
         d_noise_amp(P, r, ph, r + ph, NA);
+#ifdef BFLBM_NOISE_EARLY
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fn3[k] = NA.sj * (double)nl[k][tid];
+#else
         d_noise_head(P, NA, site, noise_index, fn3, n3);
+#endif
 #pragma unroll
         for (int k = 0; k < 3; ++k) gn3[k] = -fn3[k];
       }
       double* __restrict__ Dp = D + (long long)pc * G.plane;
-      const unsigned o = yo[1] + xo[1];
+      unsigned o = yo[1] + xo[1];
+      asm volatile("" : "+v"(o));
       if (BFLBM_ABL & 2) {
 #pragma unroll
-        for (int i = 0; i < Q; ++i) { Dp[(long long)i * G.vol + o] = mf[i] + grad_rho[0]; Dp[(long long)(i + Q) * G.vol + o] = mg[i] + grad_phi[1]; }
+        for (int i = 0; i < Q; ++i) { st(Dp + (long long)i * G.vol, o, mf[i] + grad_rho[0]); st(Dp + (long long)(i + Q) * G.vol, o, mg[i] + grad_phi[1]); }
       } else {
         SiteHydro Hy;
         SiteRecip R;
@@ -235,9 +284,16 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
           double fn[Q];
           if (MODE == 2) {
 #pragma unroll
-            for (int a = 0; a < Q; ++a) fn[a] = nb_f[a * nvol + no];
+            for (int a = 0; a < Q; ++a) fn[a] = ld(nb_f + a * nvol, no);
           } else if (MODE == 1) {
+#ifdef BFLBM_NOISE_EARLY
+            fn[0] = 0.; fn[1] = fn3[0]; fn[2] = fn3[1]; fn[3] = fn3[2];
+#pragma unroll
+            for (int a = 4; a < Q; ++a) fn[a] = NA.sf[d_noise_group(a)] * (double)nl[3 + (a - 4)][tid];
+            (void)n3;
+#else
             d_noise_f(P, NA, site, noise_index, fn3, n3, fn);
+#endif
           } else {
 #pragma unroll
             for (int a = 0; a < Q; ++a) fn[a] = 0.;
@@ -246,13 +302,13 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
           double out[Q];
           d_populations(mf, out);
 #pragma unroll
-          for (int i = 0; i < Q; ++i) Dp[(long long)i * G.vol + o] = out[i];
+          for (int i = 0; i < Q; ++i) st(Dp + (long long)i * G.vol, o, out[i]);
         }
         {
           double gn[Q];
           if (MODE == 2) {
 #pragma unroll
-            for (int a = 0; a < Q; ++a) gn[a] = nb_g[a * nvol + no];
+            for (int a = 0; a < Q; ++a) gn[a] = ld(nb_g + a * nvol, no);
           } else if (MODE == 1) {
             d_noise_g(P, NA, site, noise_index, fn3, gn);
           } else {
@@ -263,7 +319,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
           double out[Q];
           d_populations(mg, out);
 #pragma unroll
-          for (int i = 0; i < Q; ++i) Dp[(long long)(i + Q) * G.vol + o] = out[i];
+          for (int i = 0; i < Q; ++i) st(Dp + (long long)(i + Q) * G.vol, o, out[i]);
         }
       }
     }
