@@ -39,6 +39,7 @@ def cpu_baseline():
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    cores = min(cores, 16)             # a one-GPU box is given a 16-core share of its host, whatever it reports
     if cores > 1:
         n2, steps2 = 128, 20
         ob.lib().orc_set_threads(cores)

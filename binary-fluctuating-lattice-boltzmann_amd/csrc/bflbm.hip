@@ -163,7 +163,7 @@ int launch_fused(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
 
 // auto: the fused kernel is the faster one at zero noise (one HBM pass); with thermal noise the step
 // is VALU-bound (Philox + Box-Muller) and the independent 256-thread workgroups of the two-pass
-// schedule use the vector units better (measured 4690 vs 4220 MLUPS at 256^3).
+// schedule use the vector units better (measured 4670-4810 vs 4100-4290 MLUPS at 256^3).
 inline int resolved_schedule(const bflbm_ctx* c) {
   if (ref_active(c)) return 0;                   // needs the densities and their centre of mass first
   if (c->schedule != 2) return c->schedule;
