@@ -768,6 +768,7 @@ int bflbm_debug_time_kernel(bflbm_ctx* c, int which, int reps, float* ms) {
     if (which == 0) hipLaunchKernelGGL(k_pull, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
     else if (which == 1) hipLaunchKernelGGL(k_density, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->rho, c->phi, c->G, own_lo(c));
     else if (which == 3) hipLaunchKernelGGL(k_pull2, dim3((unsigned)((c->G.plane / 2 + 255) / 256), (unsigned)c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
+    else if (which == 4 && c->G.zwrap) hipLaunchKernelGGL(k_pull_rows, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
     else if (which == 2) HIP_TRY(hipMemcpyAsync(c->S[1 - c->cur], c->S[c->cur], sbytes, hipMemcpyDeviceToDevice, c->stream));
     else return fail("unknown diagnostic kernel %d", which);
   }

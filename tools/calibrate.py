@@ -9,7 +9,8 @@ lbm = pkg.BinaryLBM(n, n, n)
 lbm.LBM_init_stripe(0.5)
 sites = n ** 3
 out = {}
-for which, name, bytes_per_site in [(0, "pull_copy", 608), (1, "density", 320), (2, "memcpy_d2d", 608), (3, "pull_copy_2sites_per_thread", 608)]:
+for which, name, bytes_per_site in [(0, "pull_copy", 608), (1, "density", 320), (2, "memcpy_d2d", 608), (3, "pull_copy_2sites_per_thread", 608),
+                                     (4, "pull_copy_row_interleaved_layout", 608)]:
     ms = lbm.debug_time_kernel(which, 20)
     out[name] = {"ms": round(ms, 4), "GBps": round(sites * bytes_per_site / ms / 1e6, 1)}
 for sched in ("two_pass", "fused"):
