@@ -92,8 +92,15 @@ def main():
     if use_dist:
         import torch
         import torch.distributed as dist
+        # one rank per GPU over RCCL; BFLBM_BENCH_BACKEND=gloo rehearses several ranks on a box with fewer
+        # GPUs (ranks then share devices and the halo goes through the host) -- never a measurement
+        backend = os.environ.get("BFLBM_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         lat = pkg.SlabLattice(nx, ny, nz, params=params, schedule=a.schedule)
         eng = lat.engine
 
