@@ -184,11 +184,12 @@ int ensure_density(bflbm_ctx* c) {
 
 struct Overlap { int x0, x1, y0, y1, z0, z1; bool empty; };
 
-Overlap overlap(const bflbm_ctx* c, const bflbm_fab* b) {
+// valid cells of the box inside the lattice and inside the z range [z0, z1)
+Overlap overlap(const bflbm_ctx* c, const bflbm_fab* b, int z0, int z1) {
   Overlap o;
   o.x0 = std::max(b->vlo[0], 0); o.x1 = std::min(b->vhi[0], c->G.nx - 1);
   o.y0 = std::max(b->vlo[1], 0); o.y1 = std::min(b->vhi[1], c->G.ny - 1);
-  o.z0 = std::max(b->vlo[2], c->dom.z0); o.z1 = std::min(b->vhi[2], c->dom.z1 - 1);
+  o.z0 = std::max(b->vlo[2], z0); o.z1 = std::min(b->vhi[2], z1 - 1);
   o.empty = (o.x0 > o.x1 || o.y0 > o.y1 || o.z0 > o.z1);
   return o;
 }
@@ -204,9 +205,13 @@ int check_fab(const bflbm_fab* b) {
 
 // copy ncomp components between a host FAB and a slab-layout device array (component stride
 // dvol, plane offset dplane0 = storage plane of global z0).  to_device selects direction.
-int copy_fab(bflbm_ctx* c, double* host, const bflbm_fab* b, int ncomp, double* dev, long long dvol, int dplane0, bool to_device) {
+// whole_lattice: the device array covers global z in [0, nz) from plane 0 (reference-state fields)
+// instead of the slab's own planes.
+int copy_fab(bflbm_ctx* c, double* host, const bflbm_fab* b, int ncomp, double* dev, long long dvol, int dplane0, bool to_device,
+             bool whole_lattice = false) {
   if (check_fab(b)) return 1;
-  const Overlap o = overlap(c, b);
+  const int zlo = whole_lattice ? 0 : c->dom.z0, zhi = whole_lattice ? c->G.nz : c->dom.z1;
+  const Overlap o = overlap(c, b, zlo, zhi);
   if (o.empty) return 0;
   const size_t fx = (size_t)(b->hi[0] - b->lo[0] + 1), fy = (size_t)(b->hi[1] - b->lo[1] + 1), fz = (size_t)(b->hi[2] - b->lo[2] + 1);
   const size_t fvol = fx * fy * fz;
@@ -216,7 +221,7 @@ int copy_fab(bflbm_ctx* c, double* host, const bflbm_fab* b, int ncomp, double* 
     hipPitchedPtr hp = make_hipPitchedPtr(host + (size_t)k * fvol, fx * sizeof(double), fx * sizeof(double), fy);
     hipPitchedPtr dp = make_hipPitchedPtr(dev + (size_t)k * dvol, (size_t)c->G.nx * sizeof(double), (size_t)c->G.nx * sizeof(double), (size_t)c->G.ny);
     hipPos hpos = make_hipPos((size_t)(o.x0 - b->lo[0]) * sizeof(double), (size_t)(o.y0 - b->lo[1]), (size_t)(o.z0 - b->lo[2]));
-    hipPos dpos = make_hipPos((size_t)o.x0 * sizeof(double), (size_t)o.y0, (size_t)(o.z0 - c->dom.z0 + dplane0));
+    hipPos dpos = make_hipPos((size_t)o.x0 * sizeof(double), (size_t)o.y0, (size_t)(o.z0 - zlo + dplane0));
     p.extent = make_hipExtent((size_t)(o.x1 - o.x0 + 1) * sizeof(double), (size_t)(o.y1 - o.y0 + 1), (size_t)(o.z1 - o.z0 + 1));
     if (to_device) { p.srcPtr = hp; p.srcPos = hpos; p.dstPtr = dp; p.dstPos = dpos; p.kind = hipMemcpyHostToDevice; }
     else           { p.srcPtr = dp; p.srcPos = dpos; p.dstPtr = hp; p.dstPos = hpos; p.kind = hipMemcpyDeviceToHost; }
@@ -694,14 +699,9 @@ int bflbm_set_ref_state(bflbm_ctx* c, const double* rho_eq, const double* phi_eq
   const size_t nb = (size_t)c->G.plane * c->G.nz * sizeof(double);
   const double* src[3] = { rho_eq, phi_eq, rhot_eq };
   // the whole lattice on every slab: the lookup is shifted by the drifting centre of mass
-  bflbm_domain whole = c->dom; whole.z0 = 0; whole.z1 = c->G.nz;
-  const bflbm_domain keep = c->dom;
   for (int k = 0; k < 3; ++k) {
     if (!c->ref[k]) { HIP_TRY(hipMalloc((void**)&c->ref[k], nb)); HIP_TRY(hipMemsetAsync(c->ref[k], 0, nb, c->stream)); c->bytes += nb; }
-    c->dom = whole;
-    const int rc = copy_fab(c, const_cast<double*>(src[k]), box, 1, c->ref[k], 0, 0, true);
-    c->dom = keep;
-    if (rc) return 1;
+    if (copy_fab(c, const_cast<double*>(src[k]), box, 1, c->ref[k], 0, 0, true, true)) return 1;
   }
   return 0;
 }
