@@ -75,6 +75,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # started by hand without a launcher: start one rank per GPU as child processes (this process has not
+        # touched the GPU) and hand their exit code on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import __graft_entry__ as ge
     pkg = ge.load_package()
 
