@@ -293,6 +293,7 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   if (d->nranks == 1 && (d->z0 != 0 || d->z1 != d->n[2])) return fail("bflbm_create: a single slab must cover all of z");
   if (d->nranks > 1 && d->z1 - d->z0 < 4) return fail("bflbm_create: a slab needs at least 4 planes when nranks > 1");
   if ((long long)d->n[0] * d->n[1] * (long long)(d->z1 - d->z0 + 4) >= (1LL << 31)) return fail("bflbm_create: slab too large for 32-bit site offsets");
+  if ((long long)d->n[0] * d->n[1] >= (1LL << 28)) return fail("bflbm_create: a plane must stay below 2 GB (32-bit byte offsets inside a plane)");
   HIP_TRY(hipSetDevice(d->device));
   bflbm_ctx* c = new bflbm_ctx();
   c->prm = *p; c->dom = *d;
