@@ -105,6 +105,50 @@ __device__ __forceinline__ void noise_state(const RefState& Rf, const Geo& G, in
   ar = Rf.rho[o]; ap = Rf.phi[o]; at = Rf.rhot[o];
 }
 
+// The same addressing for the hot two-pass kernels as in the fused kernel: wave-uniform base (component
+// volume + plane, 64-bit scalar) + 32-bit per-lane BYTE offset inside the plane, so that loads and stores
+// take the scalar-base form.  The nine (dy,dx) offsets are made opaque in the block that uses them, or the
+// loop-invariant zero-extensions are hoisted and instruction selection falls back to 64-bit lane adds.
+struct SiteOff {
+  long long pl[3];     // (p+dz) * plane, dz = -1, 0, 1 (elements; uniform over the workgroup)
+  unsigned o[3][3];    // ((y+dy wrapped) * nx + (x+dx wrapped)) * 8
+};
+__device__ __forceinline__ void site_offsets(const Geo& G, int x, int y, int p, SiteOff& I) {
+  const int xm = (x == 0) ? G.nx - 1 : x - 1, xp = (x == G.nx - 1) ? 0 : x + 1;
+  const int ym = (y == 0) ? G.ny - 1 : y - 1, yp = (y == G.ny - 1) ? 0 : y + 1;
+  int pm = p - 1, pp = p + 1;
+  if (G.zwrap) { if (pm < 0) pm = G.nzs - 1; if (pp >= G.nzs) pp = 0; }
+  const int xs[3] = { xm, x, xp }, ys[3] = { ym, y, yp }, ps[3] = { pm, p, pp };
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    I.pl[a] = (long long)ps[a]*G.plane;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { I.o[a][b] = ((unsigned)(ys[a]*G.nx) + (unsigned)xs[b]) * 8u; asm volatile("" : "+v"(I.o[a][b])); }
+  }
+}
+__device__ __forceinline__ double ld_sb(const double* __restrict__ base, unsigned boff) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff);
+}
+__device__ __forceinline__ void st_sb(double* __restrict__ base, unsigned boff, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v;
+}
+// f_i(x) = S_i(x - c_i)
+__device__ __forceinline__ void pull_site(const double* __restrict__ S, const Geo& G, const SiteOff& I,
+                                          double (&fs)[Q], double (&gs)[Q]) {
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    const double* __restrict__ b = S + (long long)i*G.vol + I.pl[1 - Vel::cz[i]];
+    const unsigned o = I.o[1 - Vel::cy[i]][1 - Vel::cx[i]];
+    fs[i] = ld_sb(b, o);
+    gs[i] = ld_sb(b + (long long)Q*G.vol, o);
+  }
+}
+// nb[i] = field(x + c_i)
+__device__ __forceinline__ void gather_field(const double* __restrict__ fld, const SiteOff& I, double (&nb)[Q]) {
+#pragma unroll
+  for (int i = 0; i < Q; ++i) nb[i] = ld_sb(fld + I.pl[1 + Vel::cz[i]], I.o[1 + Vel::cy[i]][1 + Vel::cx[i]]);
+}
+
 #define BFLBM_SITE_FROM_BLOCK()                                         \
   const long long s_ = (long long)blockIdx.x*blockDim.x + threadIdx.x;  \
   if (s_ >= G.plane) return;                                            \
@@ -116,12 +160,11 @@ __device__ __forceinline__ void noise_state(const RefState& Rf, const Geo& G, in
 __global__ void __launch_bounds__(256) k_density(const double* __restrict__ S, double* __restrict__ rho,
                                                  double* __restrict__ phi, Geo G, int p0) {
   BFLBM_SITE_FROM_BLOCK();
-  SiteIdx I; site_index(G, x, y, p, I);
+  SiteOff I; site_offsets(G, x, y, p, I);
   double fs[Q], gs[Q];
   pull_site(S, G, I, fs, gs);
-  const long long o = I.row[1][1] + x;
-  rho[o] = d_density(fs);
-  phi[o] = d_density(gs);
+  st_sb(rho + I.pl[1], I.o[1][1], d_density(fs));
+  st_sb(phi + I.pl[1], I.o[1][1], d_density(gs));
 }
 
 // ---- pass B: pull, project (hydrovars), draw noise, collide, store post-collision state
@@ -134,14 +177,15 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
                                                  const double* __restrict__ injf, const double* __restrict__ injg,
                                                  Geo G, DevParams P, int p0, uint32_t noise_index, RefState Rf) {
   BFLBM_SITE_FROM_BLOCK();
-  SiteIdx I; site_index(G, x, y, p, I);
+  SiteOff I; site_offsets(G, x, y, p, I);
   double fs[Q], gs[Q];
   pull_site(S, G, I, fs, gs);
-  const long long o = I.row[1][1] + x;
-  const double r = rho[o], ph = phi[o];
+  const double r = ld_sb(rho + I.pl[1], I.o[1][1]), ph = ld_sb(phi + I.pl[1], I.o[1][1]);
   double nb[Q], grad_rho[3], grad_phi[3];
   gather_field(rho, I, nb); d_gradient(P, nb, grad_rho);
   gather_field(phi, I, nb); d_gradient(P, nb, grad_phi);
+  double* __restrict__ Dp = D + I.pl[1];
+  unsigned o = I.o[1][1];
   // noise: the momentum modes first (the projection needs them), each fluid's other modes right before
   // its relaxation; every fluid is stored as soon as it is collided -- keeps the live set small
   const long long nvol = (long long)(G.nzs - 2*G.H)*G.plane;          // injected arrays: [a][p-H][y][x]
@@ -187,7 +231,7 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
     d_relax<NOISE || INJECT>(P, m, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn, R.cs4);
     d_populations(m, fs);
 #pragma unroll
-    for (int i = 0; i < Q; ++i) D[(long long)i*G.vol + o] = fs[i];
+    for (int i = 0; i < Q; ++i) st_sb(Dp + (long long)i*G.vol, o, fs[i]);
   }
   {
     double gn[Q];
@@ -205,7 +249,7 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
     d_relax<NOISE || INJECT>(P, m, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn, R.cs4);
     d_populations(m, gs);
 #pragma unroll
-    for (int i = 0; i < Q; ++i) D[(long long)(i+Q)*G.vol + o] = gs[i];
+    for (int i = 0; i < Q; ++i) st_sb(Dp + (long long)(i+Q)*G.vol, o, gs[i]);
   }
 }
 
