@@ -31,8 +31,13 @@ BFLBM_HD uint32_t bflbm_mulhi32(uint32_t a, uint32_t b) {
 BFLBM_HD void bflbm_philox4x32_10(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
+#if defined(BFLBM_PHILOX_MUL64)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#else
     const uint32_t hi0 = bflbm_mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     const uint32_t hi1 = bflbm_mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+#endif
     const uint32_t n0 = hi1 ^ c1 ^ k0;
     const uint32_t n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
