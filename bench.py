@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=256, help="cubic box edge at N=1 / slab edge per GPU")
+    ap.add_argument("--shape", default="", help="NX,NY,NZ per GPU instead of a cube (e.g. 1024,1024,64 = configs[4]'s slab)")
     ap.add_argument("--noise", action="store_true", help="kBT=1e-5 (configs[2]) instead of zero noise")
     ap.add_argument("--init", default="stripe", choices=["stripe", "droplet", "mixture"])
     ap.add_argument("--schedule", default=os.environ.get("BFLBM_SCHEDULE", "auto"))
@@ -96,7 +97,8 @@ def main():
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     S = a.size
-    nx, ny, nz = S, S, S * world
+    sx, sy, sz = (int(v) for v in a.shape.split(",")) if a.shape else (S, S, S)
+    nx, ny, nz = sx, sy, sz * world
     par = dict(kBT=1e-5, alpha0=0.0) if a.noise else {}
     params = pkg.default_params(**par)
 

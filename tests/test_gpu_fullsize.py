@@ -134,3 +134,26 @@ def test_droplet_notebook_centre_of_mass_after_20000_steps(pkg):
     assert np.allclose(np.sort(ev_d), np.sort([0.03491747, 0.03496081, 0.03491747]), rtol=0, atol=6e-9), ev_d
     assert np.allclose(np.sort(axes_d), np.sort([0.1668965, 0.16700005, 0.1668965]), rtol=0, atol=3e-7), axes_d
     lbm.close()
+
+
+def test_config5_slab_shape_1024x1024(pkg):
+    """configs[4]: 1024 x 1024 planes (the weak-scaling slab of the 8-GPU case, shortened in z).  2048 tile
+    columns, 8 MB planes: the fused kernel, the two-pass kernels and a ring of two slabs with halo exchange
+    must produce identical doubles; mass is conserved."""
+    nx, ny, nz = 1024, 1024, 12
+    res = {}
+    for schedule in ("two_pass", "fused"):
+        lbm = pkg.BinaryLBM(nx, ny, nz, params=pkg.default_params(alpha0=2.0), schedule=schedule)
+        lbm.LBM_init_droplet(0.01)                 # radius 10 cells around (512, 512, 512 -> wrapped z)
+        m0 = lbm.mass()
+        lbm.LBM_timestep(4)
+        m1 = lbm.mass()
+        assert abs(m1[0] - m0[0]) <= 1e-12 * m0[0] and abs(m1[1] - m0[1]) <= 1e-12 * m0[1]
+        res[schedule] = lbm.LBM_hydrovars_density()
+        lbm.close()
+    assert np.array_equal(res["two_pass"], res["fused"])
+    ring = pkg.RingLBM(nx, ny, nz, nslabs=2, params=pkg.default_params(alpha0=2.0))
+    ring.LBM_init_droplet(0.01)
+    ring.LBM_timestep(4)
+    assert np.array_equal(ring.LBM_hydrovars_density(), res["fused"])
+    ring.close()
