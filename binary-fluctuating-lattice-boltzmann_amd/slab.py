@@ -27,6 +27,8 @@ def slab_bounds(nz, nranks, rank):
 class _Protocol:
     """The per-step and upload protocols, independent of how buffers travel."""
 
+    overlap = True      # False: exchange after the whole sweep (measurement of what the overlap buys)
+
     def __init__(self, engine):
         self.engine = engine
 
@@ -43,8 +45,13 @@ class _Protocol:
         for _ in range(int(nsteps)):
             self._prepare_ref()
             e.step_boundary()
-            self._post(_lib.HALO_NEXT)
-            e.step_interior()
+            if self.overlap:
+                self._post(_lib.HALO_NEXT)
+                e.step_interior()
+            else:
+                e.step_interior()
+                e.sync()                       # nothing of the sweep is left to hide the exchange behind
+                self._post(_lib.HALO_NEXT)
             self._complete(_lib.HALO_NEXT)
             e.step_finish()
 
