@@ -119,6 +119,8 @@ class BinaryLBM(_DropletMixin):
     # -- lifetime -------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
+            for d in list(getattr(self, "_dependents", [])):   # e.g. structure-factor accumulators living on this context
+                d.close()
             if not getattr(self, "_borrowed", False):
                 self.lib.bflbm_destroy(self._h)
             self._h = None
@@ -359,6 +361,9 @@ class RingLBM(_DropletMixin):
 
     def close(self):
         if getattr(self, "_h", None):
+            for s in self.slabs:
+                for d in list(getattr(s, "_dependents", [])):
+                    d.close()
             self.lib.bflbm_ring_destroy(self._h)
             self._h = None
             for s in self.slabs:

@@ -89,11 +89,17 @@ class DeviceStructFact(StructFact):
         h = ctypes.c_void_p()
         _lib.check(lbm.lib.bflbm_sf_create(lbm._h, n, a, b, sc, ctypes.byref(h)))
         self._h = h
+        if not hasattr(lbm, "_dependents"):
+            lbm._dependents = []
+        lbm._dependents.append(self)             # closed before the context it lives on
 
     def close(self):
         if getattr(self, "_h", None):
             self._libh.bflbm_sf_destroy(self._h)
             self._h = None
+            deps = getattr(self.lbm, "_dependents", [])
+            if self in deps:
+                deps.remove(self)
 
     def __del__(self):
         try:

@@ -61,6 +61,12 @@ def test_device_structure_factor_of_hydrovsbar_and_errors(pkg):
     dev.fort_structure(); host.fort_structure(lbm.LBM_hydrovars_density(), 0)
     _agree(dev.mean(1).real, host.mean(1).real)
     dev.close()
+    # closing the lattice first releases the accumulator that lives on it
+    dev2 = pkg.structfact.DeviceStructFact(lbm, names, lb_hydrovars=True)
+    lbm.close()
+    assert dev2._h is None
+    dev2.close()
+    lbm = pkg.BinaryLBM(8, 8, 8)
     slab = pkg.BinaryLBM(8, 8, 8, z0=0, z1=4, rank=0, nranks=2)
     with pytest.raises(pkg.BflbmError, match="whole lattice"):
         pkg.structfact.DeviceStructFact(slab, pkg.plotfile.variable_names(22))
