@@ -330,6 +330,7 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   c->bytes = 2 * sbytes + 2 * fbytes + c->partial_n * 5 * sizeof(double);
   // halo planes must never hold NaN garbage that a reduction could touch
   hipMemsetAsync(c->S[0], 0, sbytes, c->stream);
+  { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && ncu > 0) g_fused_ncu = ncu; }
   hipMemsetAsync(c->S[1], 0, sbytes, c->stream);
   hipMemsetAsync(c->rho, 0, fbytes, c->stream);
   hipMemsetAsync(c->phi, 0, fbytes, c->stream);

@@ -347,6 +347,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 static unsigned long long* g_stamp_buf = nullptr;
 static int g_stamp_n = 0;
 #endif
+static int g_fused_ncu = 0;     // compute units of the device (set at context creation)
 // returns non-zero on launch failure
 static inline int fused_launch(const double* S, double* D, const double* injf, const double* injg,
                                const Geo& G, const DevParams& P, int pa, int pb,
@@ -360,21 +361,33 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   F.ncols = F.ntx * F.nty;
   F.pa = pa; F.pb = pb;
   const int np = pb - pa;
-  // enough chunks to fill the chip a few times over (2 workgroups resident per CU), chunks of
-  // >= 16 planes; BFLBM_FUSED_WG overrides the target workgroup count (tuning only)
   static const int want_env = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 0; }();
-  // Single slab: at least one workgroup per CU (256) and marches of at most 256 planes (longer ones
-  // let neighbouring workgroups drift apart and lose L2 sharing: 256^3 -> 2 chunks x 128 columns,
-  // 512^3 -> 2 chunks x 512 columns; measured best on MI355X).  Slab of a multi-GPU run: ~1024
-  // shorter workgroups, so that the RCCL copy kernels of the overlapped exchange, which need a few
-  // CUs of their own, delay at most a short tail of the interior sweep.
+  // Chunking.  One workgroup is resident per CU, so the launch runs in rounds of `ncu` workgroups and costs
+  // about  rounds x (planes per chunk + 1)  plane marches (a chunk of L planes marches L+2, the two extra
+  // ones pull only).  Pick the chunk count that minimises this: 256^3 -> 128 columns x 2 chunks = one full
+  // round; 192^3 -> 72 columns x 7 chunks = 504 workgroups in 2 rounds of 30 planes instead of 288 in
+  // "1.1" rounds of 50.  Marches longer than 256 planes are avoided on a single slab (neighbouring
+  // workgroups drift apart and lose L2 sharing; measured on MI355X); a slab of a multi-GPU run is cut
+  // into >= 3 rounds of shorter workgroups so that the RCCL copy kernels of the overlapped exchange, which
+  // need a few CUs of their own, delay at most a short tail of the interior sweep.
+  // BFLBM_FUSED_WG overrides the target workgroup count (tuning only).
+  const int ncu = g_fused_ncu > 0 ? g_fused_ncu : 256;
+  const int maxchunks = std::max(1, (np + 15) / 16);
   int nchunks;
-  if (want_env > 0)   nchunks = (want_env + F.ncols - 1) / F.ncols;
-  else if (G.zwrap)   nchunks = std::max((256 + F.ncols - 1) / F.ncols, (np + 255) / 256);
-  else                nchunks = (1024 + F.ncols - 1) / F.ncols;
-  const int maxchunks = (np + 15) / 16;
-  if (nchunks > maxchunks) nchunks = maxchunks;
-  if (nchunks < 1) nchunks = 1;
+  if (want_env > 0) {
+    nchunks = std::min(maxchunks, std::max(1, (want_env + F.ncols - 1) / F.ncols));
+  } else {
+    long long best = -1; nchunks = 1;
+    for (int k = 1; k <= maxchunks; ++k) {
+      const int lz = (np + k - 1) / k, chunks = (np + lz - 1) / lz;
+      if (chunks != k) continue;                                  // same partition as a smaller k
+      if (G.zwrap && lz > 256 && k < maxchunks) continue;
+      const long long total = (long long)F.ncols * chunks, rounds = (total + ncu - 1) / ncu;
+      if (!G.zwrap && rounds < 3 && k < maxchunks) continue;
+      const long long cost = rounds * (lz + 1);
+      if (best < 0 || cost < best) { best = cost; nchunks = k; }
+    }
+  }
   F.lz = (np + nchunks - 1) / nchunks;
   F.nchunks = (np + F.lz - 1) / F.lz;
   F.cstride = F.lz;
