@@ -372,7 +372,7 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   // need a few CUs of their own, delay at most a short tail of the interior sweep.
   // BFLBM_FUSED_WG overrides the target workgroup count (tuning only).
   const int ncu = g_fused_ncu > 0 ? g_fused_ncu : 256;
-  const int maxchunks = std::max(1, (np + 15) / 16);
+  const int maxchunks = std::max(1, np / 2);                     // small lattices: short chunks buy parallelism
   int nchunks;
   if (want_env > 0) {
     nchunks = std::min(maxchunks, std::max(1, (want_env + F.ncols - 1) / F.ncols));
