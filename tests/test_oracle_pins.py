@@ -256,3 +256,15 @@ def test_threaded_oracle_is_bit_identical(ob):
     ob.lib().orc_set_threads(1)
     for x, y in zip(*outs):
         assert np.array_equal(x, y)
+
+
+def test_golden_v2_matches_current_oracle(ob):
+    """tests/golden/oracle_golden_v2.npz (SURVEY 8c's fixture list; tests/golden/make_golden_v2.py): rebuilt
+    from the current oracle, every entry -- arrays and SHA-256 digests -- must be unchanged."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden_v2 as mg
+    stored, fresh = mg.load(), mg.build()
+    assert sorted(stored) == sorted(fresh) and len(stored) > 150
+    for k in stored:
+        assert np.array_equal(stored[k], fresh[k]), k
