@@ -306,15 +306,24 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   G.nzs = c->nzl + 2 * G.H;
   G.z0 = d->z0;
   G.plane = (long long)G.nx * G.ny;
-  // component stride: padded by 65 cache lines so that the 38 component arrays of a power-of-two
-  // lattice do not all start on the same memory channel / L2 set.  Measured on MI355X (256^3):
-  // pull-copy 1.96 -> 1.77 ms, fused step 2.57 -> 2.35 ms (BFLBM_PAD = doubles, tuning override).
+  // component stride: padded so that the 38 component arrays of a power-of-two lattice do not all start
+  // on the same memory channel / L2 set.  Measured on MI355X (256^3): no pad -> 65 lines (1040 doubles):
+  // pull-copy 1.96 -> 1.77 ms, fused step 2.57 -> 2.35 ms; a scan with reproducible placement (one
+  // allocation, below) gives 0: 6780, 1040: 6870-6940, 65552: 6935-7000, 262160: 6970, 1048592: 6730 MLUPS
+  // -> 65552 doubles = 512 KB + one line (BFLBM_PAD = doubles, tuning override).
   static const long long pad = [] { const char* e = getenv("BFLBM_PAD"); return e ? atoll(e) : 1040LL; }();
   G.vol = G.plane * G.nzs + pad;
   const size_t sbytes = (size_t)2 * Q * G.vol * sizeof(double);
   const size_t fbytes = (size_t)G.vol * sizeof(double);
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipMalloc((void**)&c->S[k], sbytes);
+  // Both state buffers come from ONE allocation with buffer B displaced by 33280 doubles (260 KB) from the
+  // end of A.  With two separate allocations the relative placement of the read and the write stream of a
+  // component varied from process to process and with it the step time (6510-7190 MLUPS at 256^3 on one
+  // box); inside one allocation it is reproducible to 0.3 %, 520 doubles is a bad displacement (-4 %),
+  // anything from 25k to 1M doubles is equally good (BFLBM_AB_OFF = doubles, tuning override).
+  static const long long ab_off = [] { const char* e = getenv("BFLBM_AB_OFF"); return e ? atoll(e) : 33280LL; }();
+  e = hipMalloc((void**)&c->S[0], 2 * sbytes + (size_t)ab_off * sizeof(double));
+  if (e == hipSuccess) c->S[1] = c->S[0] + (size_t)2 * Q * G.vol + ab_off;
   if (e == hipSuccess) e = hipMalloc((void**)&c->rho, fbytes);
   if (e == hipSuccess) e = hipMalloc((void**)&c->phi, fbytes);
   c->partial_n = (size_t)((G.plane + 255) / 256) * (size_t)c->nzl;
@@ -343,7 +352,7 @@ int bflbm_destroy(bflbm_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->dom.device);
   if (c->stream && c->own_stream) hipStreamSynchronize(c->stream);
-  for (int k = 0; k < 2; ++k) if (c->S[k]) hipFree(c->S[k]);
+  if (c->S[0]) hipFree(c->S[0]);                 // S[1] lives in the same allocation
   if (c->rho) hipFree(c->rho);
   if (c->phi) hipFree(c->phi);
   if (c->injf) hipFree(c->injf);
