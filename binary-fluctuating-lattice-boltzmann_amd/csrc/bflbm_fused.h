@@ -56,9 +56,6 @@ __device__ __forceinline__ bool fused_map(const FusedGrid& F, int b, int& col, i
 #else
 #define STAMP(k) do {} while (0)
 #endif
-#ifndef BFLBM_VARIANT
-#define BFLBM_VARIANT 0   // timing experiments: 2 non-temporal stores, 4 own loads f first then g, 8 ring sums before own sums
-#endif
 #ifndef BFLBM_ABL
 #define BFLBM_ABL 0   // ablation switches for timing experiments only (results become wrong)
 #endif
@@ -103,9 +100,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   const unsigned xo[3] = { (unsigned)wrapx(x - 1) * 8u, (unsigned)x * 8u, (unsigned)wrapx(x + 1) * 8u };
   const unsigned yo[3] = { (unsigned)(wrapy(y - 1) * G.nx) * 8u, (unsigned)(y * G.nx) * 8u, (unsigned)(wrapy(y + 1) * G.nx) * 8u };
   auto ld = [](const double* __restrict__ base, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff); };
-  auto st = [](double* __restrict__ base, unsigned boff, double v) {
-    double* q_ = reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff);
-    if (BFLBM_VARIANT & 2) __builtin_nontemporal_store(v, q_); else *q_ = v; };
+  auto st = [](double* __restrict__ base, unsigned boff, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v; };
   // ---- ring half-task of this thread: lanes 0..nper-1 of every wave; the lower half of the waves sums
   // fluid f, the upper half fluid g, so the fluid (and with it the load base) is wave-uniform
   const int nring = 2 * (aw + 2) + 2 * ah;
@@ -171,14 +166,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
         const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
         const unsigned o = oo[1 - Vel::cy[i]][1 - Vel::cx[i]];
         cf[i] = ld(b, o);
-        if (!(BFLBM_VARIANT & 4)) cg[i] = ld(b + (long long)Q * G.vol, o);
-      }
-      if (BFLBM_VARIANT & 4) {
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-          const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)(i + Q) * G.vol;
-          cg[i] = ld(b, oo[1 - Vel::cy[i]][1 - Vel::cx[i]]);
-        }
+        cg[i] = ld(b + (long long)Q * G.vol, o);
       }
     } else {
 #pragma unroll
@@ -225,14 +213,9 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #pragma unroll
       for (int i = 0; i < Q; ++i) r += fs[i];
       return r; };
-#if (BFLBM_VARIANT & 8)
-    if (has_task) rp[slot][hfl][lhalo] = density(hv);
-    if (loader) { rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg); }
-#else
     // own sums first: their loads were issued first, the ring loads are still landing meanwhile
     if (loader) { rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg); }
     if (has_task) rp[slot][hfl][lhalo] = density(hv);
-#endif
     STAMP(1);                                   // data arrived, sums done
     __syncthreads();
     STAMP(2);                                   // barrier
