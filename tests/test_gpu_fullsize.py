@@ -157,3 +157,20 @@ def test_config5_slab_shape_1024x1024(pkg):
     ring.LBM_timestep(4)
     assert np.array_equal(ring.LBM_hydrovars_density(), res["fused"])
     ring.close()
+
+
+def test_flat_interface_notebook_height_full_box(pkg):
+    """Flat_Interface.ipynb cell 4 (run of the reference, 2025-11-14): the reference's flat-interface box
+    8 x 256 x 64 (main_run_job.cpp:128), alpha0 = 1.5, frame 2000 -> the rho = 1.05 contour sits at
+    47.86628666 for every (x, y) (parameters not printed in the notebook: kappa = 0.1, rho_lo = 0.1,
+    rho_hi = 3.0, see tests/test_oracle_pins.py::test_flat_interface_notebook_height)."""
+    lbm = pkg.BinaryLBM(8, 256, 64, params=pkg.default_params(alpha0=1.5, kappa=0.1, rho_lo=0.1, rho_hi=3.0))
+    lbm.LBM_init_stripe(0.5)
+    lbm.LBM_timestep(2000)
+    rho = lbm.LBM_hydrovars(ncomp=1)[0]                    # [z, y, x]
+    a, b = rho[47], rho[48]
+    height = 47 + (1.05 - a) / (b - a)
+    assert np.all((a - 1.05) * (b - 1.05) < 0)
+    assert {"%.8f" % v for v in height.ravel()} == {"47.86628666"}
+    assert np.all(rho == rho[:, :1, :1])                   # uniform in x and y, bit for bit
+    lbm.close()

@@ -268,3 +268,50 @@ def test_golden_v2_matches_current_oracle(ob):
     assert sorted(stored) == sorted(fresh) and len(stored) > 150
     for k in stored:
         assert np.array_equal(stored[k], fresh[k]), k
+
+
+def _contour_heights(rho_z, level):
+    """z positions where rho crosses `level`, linear interpolation between cells (skimage.measure.find_contours)."""
+    out = []
+    for k in range(len(rho_z) - 1):
+        a, b = rho_z[k], rho_z[k + 1]
+        if (a - level) * (b - level) < 0:
+            out.append(k + (level - a) / (b - a))
+    return out
+
+
+def test_flat_interface_notebook_height(ob):
+    """Flat_Interface.ipynb cell 4, a run of the reference itself (2025-11-14): 8x256x64 stripe, alpha0 = 1.5,
+    kBT = 0, frame 2000, height of the rho = 1.05 contour = 47.86628666 at every (x, y).  The simulation's
+    rho_lo, rho_hi and kappa are not printed; 0.1, 3.0 (cell 7's values) and 0.1 reproduce all ten digits
+    (tools/flat_interface_probe.py).  The state is uniform in x and y, so a 1x1x64 column gives the same
+    doubles as the full box (the GPU test runs the full box)."""
+    ref = ob.OracleLattice(1, 1, 64, ob.default_params(alpha0=1.5, kappa=0.1, rho_lo=0.1, rho_hi=3.0))
+    ref.init_stripe(0.5)
+    for _ in range(2000):
+        ref.timestep()
+    lo, hi = _contour_heights(ref.hbar[0][:, 0, 0], 1.05)
+    assert "%.8f" % hi == "47.86628666"
+    assert abs(lo + hi - 64.0) < 1e-9                      # the two interfaces are mirror images about z = 32
+    # cell 7 evaluates the same kind of run at the level (0.1 + 3.0)/2
+    assert 47.5 < _contour_heights(ref.hbar[0][:, 0, 0], 1.55)[1] < 47.55
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("BFLBM_SLOW_TESTS"), reason="3 minutes on 8 cores; set BFLBM_SLOW_TESTS=1")
+def test_surface_tension_notebook_system0_on_the_oracle(ob):
+    """Surface_Tension.ipynb cell 13, system 0 (32^3 droplet, alpha0 = 1.5, rho_hi = 3, kappa = 0.1, r = 0.2, frame
+    20000): the oracle itself against the reference's recorded densities (the GPU test covers all nine systems;
+    oracle and GPU agree bit for bit: 0.015052155677499774, 3.5074475104542557, 3.022225511714613,
+    -0.0030774512154752736 on both)."""
+    ob.lib().orc_set_threads(8)
+    try:
+        ref = ob.OracleLattice(32, 32, 32, ob.default_params(alpha0=1.5, kappa=0.1, rho_hi=3.0))
+        ref.init_droplet(0.2)
+        for _ in range(20000):
+            ref.timestep()
+    finally:
+        ob.lib().orc_set_threads(1)
+    got = np.array([ref.hbar[0][16, 16, 0], ref.hbar[0][16, 16, 16], ref.hbar[1][16, 16, 0], ref.hbar[1][16, 16, 16]])
+    want = np.array([0.015052155677499688, 3.507447510454257, 3.0222255117146184, -0.003077451215475287])
+    assert np.all(np.abs(got - want) <= 1e-13 * np.abs(want))
+    assert list(got) == [0.015052155677499774, 3.5074475104542557, 3.022225511714613, -0.0030774512154752736]
