@@ -105,3 +105,17 @@ def test_surface_tension_notebook_numbers(pkg, alpha0, kappa, nc, systems, radii
     # the radii the notebook quotes are tanh fits of the same fields (cell 8: scipy curve_fit); the device fit
     # of the same model finds them to the digits quoted (8 significant)
     np.testing.assert_allclose(fits, radii, rtol=2e-6)
+
+
+def test_surface_tension_notebook_cell4_maxima(pkg):
+    """Cell 4 (alpha0 = 2, rho_hi = 3, r = 0.2, 32^3; kappa = 3 identified from the printed initial maximum):
+    'max rho at step0: 2.998 dimensionless, step1: 3.648 dimensionless' and the conserved-mass ratio '1.000e+00'."""
+    lbm = pkg.BinaryLBM(N, N, N, params=pkg.default_params(rho_hi=3.0, alpha0=2.0, kappa=3.0))
+    lbm.LBM_init_droplet(0.2)
+    rho0 = lbm.LBM_hydrovars(ncomp=1)[0]
+    m0 = lbm.mass()[0]
+    lbm.LBM_timestep(20000)
+    rho1 = lbm.LBM_hydrovars(ncomp=1)[0]
+    assert "%.3f" % rho0.max() == "2.998" and "%.3f" % rho1.max() == "3.648"
+    assert "%.3e" % (lbm.mass()[0] / m0) == "1.000e+00"
+    lbm.close()
