@@ -88,6 +88,12 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd).returncode)
 
+    # Libraries print banners on the C-level stdout (RCCL: "Librccl path : ..."); the contract is ONE JSON line
+    # on stdout, so everything until that line goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import __graft_entry__ as ge
     pkg = ge.load_package()
 
@@ -193,7 +199,10 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         import torch.distributed as dist
         dist.barrier()
