@@ -374,6 +374,9 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   // need a few CUs of their own, delay at most a short tail of the interior sweep.
   // BFLBM_FUSED_WG overrides the target workgroup count (tuning only).
   const int ncu = g_fused_ncu > 0 ? g_fused_ncu : 256;
+  // BFLBM_SLAB_ROUNDS: minimum number of rounds of the interior sweep of a slab (default 3; tuning knob for
+  // real multi-GPU runs: fewer rounds = less look-ahead overhead, more = shorter tail behind the RCCL kernels)
+  static const int min_slab_rounds = [] { const char* e = getenv("BFLBM_SLAB_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
   const int maxchunks = std::max(1, np / 2);                     // small lattices: short chunks buy parallelism
   int nchunks;
   if (want_env > 0) {
@@ -385,7 +388,7 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
       if (chunks != k) continue;                                  // same partition as a smaller k
       if (G.zwrap && lz > 256 && k < maxchunks) continue;
       const long long total = (long long)F.ncols * chunks, rounds = (total + ncu - 1) / ncu;
-      if (!G.zwrap && rounds < 3 && k < maxchunks) continue;
+      if (!G.zwrap && rounds < min_slab_rounds && k < maxchunks) continue;
       const long long cost = rounds * (lz + 1);
       if (best < 0 || cost < best) { best = cost; nchunks = k; }
     }
