@@ -134,7 +134,17 @@ RefState ref_state(const bflbm_ctx* c) {
   if (kind == 1) return R;
   double rel[3];
   for (int d = 0; d < 3; ++d) rel[d] = c->com[d] - (kind == 0 ? c->com_ref[d] : 0.);
-  R.sx = (int)rel[0]; R.sy = (int)rel[1]; R.sz = (int)rel[2];     // static_cast<int>, :94-96
+  // static_cast<int> (:94-96), then reduced modulo the lattice: the reference wraps the shifted index ONCE
+  // (:98-103), which is only in range for |shift| < n -- beyond that it reads out of bounds.  The reduction
+  // changes nothing for |shift| < n and keeps the kernel's single wrap sufficient for any centre of mass
+  // (prepare_ref refuses a non-finite one).
+  const int n[3] = { c->G.nx, c->G.ny, c->G.nz };
+  int sh[3];
+  for (int d = 0; d < 3; ++d) {
+    const double t = std::trunc(rel[d]);
+    sh[d] = (int)std::fmod(t, (double)n[d]);                       // in (-n, n), sign of the shift kept
+  }
+  R.sx = sh[0]; R.sy = sh[1]; R.sz = sh[2];
   return R;
 }
 
@@ -207,8 +217,10 @@ int check_fab(const bflbm_fab* b) {
 // dvol, plane offset dplane0 = storage plane of global z0).  to_device selects direction.
 // whole_lattice: the device array covers global z in [0, nz) from plane 0 (reference-state fields)
 // instead of the slab's own planes.
+// dense: the device array has rows of nx elements (observable outputs, injected noise, reference state)
+// instead of the resident arrays' pitch.
 int copy_fab(bflbm_ctx* c, double* host, const bflbm_fab* b, int ncomp, double* dev, long long dvol, int dplane0, bool to_device,
-             bool whole_lattice = false) {
+             bool whole_lattice = false, bool dense = false) {
   if (check_fab(b)) return 1;
   const int zlo = whole_lattice ? 0 : c->dom.z0, zhi = whole_lattice ? c->G.nz : c->dom.z1;
   const Overlap o = overlap(c, b, zlo, zhi);
@@ -219,7 +231,8 @@ int copy_fab(bflbm_ctx* c, double* host, const bflbm_fab* b, int ncomp, double* 
     hipMemcpy3DParms p;
     memset(&p, 0, sizeof p);
     hipPitchedPtr hp = make_hipPitchedPtr(host + (size_t)k * fvol, fx * sizeof(double), fx * sizeof(double), fy);
-    hipPitchedPtr dp = make_hipPitchedPtr(dev + (size_t)k * dvol, (size_t)c->G.nx * sizeof(double), (size_t)c->G.nx * sizeof(double), (size_t)c->G.ny);
+    const size_t drow = (size_t)(dense ? c->G.nx : c->G.pitch) * sizeof(double);
+    hipPitchedPtr dp = make_hipPitchedPtr(dev + (size_t)k * dvol, drow, drow, (size_t)c->G.ny);
     hipPos hpos = make_hipPos((size_t)(o.x0 - b->lo[0]) * sizeof(double), (size_t)(o.y0 - b->lo[1]), (size_t)(o.z0 - b->lo[2]));
     hipPos dpos = make_hipPos((size_t)o.x0 * sizeof(double), (size_t)o.y0, (size_t)(o.z0 - zlo + dplane0));
     p.extent = make_hipExtent((size_t)(o.x1 - o.x0 + 1) * sizeof(double), (size_t)(o.y1 - o.y0 + 1), (size_t)(o.z1 - o.z0 + 1));
@@ -292,8 +305,8 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   if (d->z0 < 0 || d->z1 > d->n[2] || d->z1 <= d->z0) return fail("bflbm_create: bad slab [%d,%d) of nz=%d", d->z0, d->z1, d->n[2]);
   if (d->nranks == 1 && (d->z0 != 0 || d->z1 != d->n[2])) return fail("bflbm_create: a single slab must cover all of z");
   if (d->nranks > 1 && d->z1 - d->z0 < 4) return fail("bflbm_create: a slab needs at least 4 planes when nranks > 1");
-  if ((long long)d->n[0] * d->n[1] * (long long)(d->z1 - d->z0 + 4) >= (1LL << 31)) return fail("bflbm_create: slab too large for 32-bit site offsets");
-  if ((long long)d->n[0] * d->n[1] >= (1LL << 28)) return fail("bflbm_create: a plane must stay below 2 GB (32-bit byte offsets inside a plane)");
+  if ((long long)(d->n[0] + 15) * d->n[1] * (long long)(d->z1 - d->z0 + 4) >= (1LL << 31)) return fail("bflbm_create: slab too large for 32-bit site offsets");
+  if ((long long)(d->n[0] + 15) * d->n[1] >= (1LL << 28)) return fail("bflbm_create: a plane must stay below 2 GB (32-bit byte offsets inside a plane)");
   HIP_TRY(hipSetDevice(d->device));
   bflbm_ctx* c = new bflbm_ctx();
   c->prm = *p; c->dom = *d;
@@ -305,7 +318,13 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   G.H = G.zwrap ? 0 : 2;
   G.nzs = c->nzl + 2 * G.H;
   G.z0 = d->z0;
-  G.plane = (long long)G.nx * G.ny;
+  // rows of the resident arrays start on 128-byte lines for any nx.  Measured against dense rows on one box
+  // (A/B of the two libraries, +-0.5 %): 250^3 +1.5 %, 300^3 +3.9 %, 257^3 +2.7 %, no change when nx is a
+  // multiple of 16 (pitch == nx, same code path).  Most of what such sizes lose against 256^3 is partial
+  // tiles, not alignment.  Dense layouts (dplane) are kept for everything that crosses the ABI.
+  G.pitch = (G.nx > 16) ? ((G.nx + 15) & ~15) : G.nx;
+  G.plane = (long long)G.pitch * G.ny;
+  G.dplane = (long long)G.nx * G.ny;
   // component stride: padded so that the 38 component arrays of a power-of-two lattice do not all start
   // on the same memory channel / L2 set.  Measured on MI355X (256^3): no pad -> 65 lines (1040 doubles):
   // pull-copy 1.96 -> 1.77 ms, fused step 2.57 -> 2.35 ms; a scan with reproducible placement (one
@@ -451,7 +470,7 @@ int bflbm_init_droplet(bflbm_ctx* c, double r_frac) {
   const double R = r_frac * nx;                  // LBM_binary.H:714 (box[0])
   const double rho_t = P.rho_hi + P.rho_lo;
   const int npe = c->G.nzs + 2;
-  const size_t plane = (size_t)c->G.plane;
+  const size_t plane = (size_t)c->G.dplane;       // host table: dense planes (k_init reads it that way)
   std::vector<double> fld(plane * npe);
   auto work = [&](int pa, int pb) {
     for (int pe = pa; pe < pb; ++pe) {
@@ -620,13 +639,13 @@ static int observe(bflbm_ctx* c, int what, int ncomp_out, double* dst, double* d
   if (what == 1) hipLaunchKernelGGL((k_observe<1>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj, Rf);
   if (what == 2) hipLaunchKernelGGL((k_observe<2>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, out, c->G, c->dp, own_lo(c), idx, ncomp_out, inj, Rf);
   HIP_TRY(hipGetLastError());
-  const long long ovol = (long long)c->nzl * c->G.plane;
+  const long long ovol = (long long)c->nzl * c->G.dplane;
   if (what == 1) {
-    if (dst && copy_fab(c, dst, box, Q, out, ovol, 0, false)) return 1;
-    if (dst2 && copy_fab(c, dst2, box, Q, out + (size_t)Q * ovol, ovol, 0, false)) return 1;
+    if (dst && copy_fab(c, dst, box, Q, out, ovol, 0, false, false, true)) return 1;
+    if (dst2 && copy_fab(c, dst2, box, Q, out + (size_t)Q * ovol, ovol, 0, false, false, true)) return 1;
     return 0;
   }
-  return copy_fab(c, dst, box, ncomp_host, out, ovol, 0, false);
+  return copy_fab(c, dst, box, ncomp_host, out, ovol, 0, false, false, true);
 }
 
 int bflbm_get_hydrovsbar(bflbm_ctx* c, double* dst, int ncomp, const bflbm_fab* box) {
@@ -649,11 +668,11 @@ int bflbm_inject_noise(bflbm_ctx* c, const double* fn, const double* gn, const b
   if (!c) return fail("null context");
   if (!fn || !gn) { c->inject = false; return 0; }
   HIP_TRY(hipSetDevice(c->dom.device));
-  const size_t nb = (size_t)Q * c->nzl * (size_t)c->G.plane * sizeof(double);
+  const size_t nb = (size_t)Q * c->nzl * (size_t)c->G.dplane * sizeof(double);
   if (!c->injf) { HIP_TRY(hipMalloc((void**)&c->injf, nb)); HIP_TRY(hipMalloc((void**)&c->injg, nb)); c->bytes += 2 * nb; }
-  const long long ovol = (long long)c->nzl * c->G.plane;
-  if (copy_fab(c, const_cast<double*>(fn), box, Q, c->injf, ovol, 0, true)) return 1;
-  if (copy_fab(c, const_cast<double*>(gn), box, Q, c->injg, ovol, 0, true)) return 1;
+  const long long ovol = (long long)c->nzl * c->G.dplane;
+  if (copy_fab(c, const_cast<double*>(fn), box, Q, c->injf, ovol, 0, true, false, true)) return 1;
+  if (copy_fab(c, const_cast<double*>(gn), box, Q, c->injg, ovol, 0, true, false, true)) return 1;
   c->inject = true;
   return 0;
 }
@@ -699,6 +718,8 @@ static int prepare_ref(bflbm_ctx* c) {
   double r[5];
   if (reduce5(c, r)) return 1;
   for (int d = 0; d < 3; ++d) c->com[d] = r[2 + d] / r[0];
+  for (int d = 0; d < 3; ++d)
+    if (!std::isfinite(c->com[d])) return fail("reference-state noise: the centre of mass of fluid f is not finite (total mass %.3g)", r[0]);
   c->com_valid = true;
   return 0;
 }
@@ -707,12 +728,12 @@ int bflbm_set_ref_state(bflbm_ctx* c, const double* rho_eq, const double* phi_eq
   if (!c || !rho_eq || !phi_eq || !rhot_eq) return fail("null argument");
   if (check_fab(box)) return 1;
   HIP_TRY(hipSetDevice(c->dom.device));
-  const size_t nb = (size_t)c->G.plane * c->G.nz * sizeof(double);
+  const size_t nb = (size_t)c->G.dplane * c->G.nz * sizeof(double);
   const double* src[3] = { rho_eq, phi_eq, rhot_eq };
   // the whole lattice on every slab: the lookup is shifted by the drifting centre of mass
   for (int k = 0; k < 3; ++k) {
     if (!c->ref[k]) { HIP_TRY(hipMalloc((void**)&c->ref[k], nb)); HIP_TRY(hipMemsetAsync(c->ref[k], 0, nb, c->stream)); c->bytes += nb; }
-    if (copy_fab(c, const_cast<double*>(src[k]), box, 1, c->ref[k], 0, 0, true, true)) return 1;
+    if (copy_fab(c, const_cast<double*>(src[k]), box, 1, c->ref[k], 0, 0, true, true, true)) return 1;
   }
   return 0;
 }
@@ -734,6 +755,7 @@ int bflbm_ref_state_active(const bflbm_ctx* c, int* active) {
 int bflbm_set_com(bflbm_ctx* c, const double com[3]) {
   if (!c || !com) return fail("null argument");
   if (c->step_open) return fail("bflbm_set_com inside an open step");
+  for (int d = 0; d < 3; ++d) if (!std::isfinite(com[d])) return fail("bflbm_set_com: centre of mass is not finite");
   for (int d = 0; d < 3; ++d) c->com[d] = com[d];
   c->com_valid = true;
   return 0;
@@ -778,8 +800,8 @@ int bflbm_debug_time_kernel(bflbm_ctx* c, int which, int reps, float* ms) {
     if (r == 0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (which == 0) hipLaunchKernelGGL(k_pull, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
     else if (which == 1) hipLaunchKernelGGL(k_density, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->rho, c->phi, c->G, own_lo(c));
-    else if (which == 3) hipLaunchKernelGGL(k_pull2, dim3((unsigned)((c->G.plane / 2 + 255) / 256), (unsigned)c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
-    else if (which == 4 && c->G.zwrap) hipLaunchKernelGGL(k_pull_rows, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
+    else if (which == 3 && c->G.pitch == c->G.nx) hipLaunchKernelGGL(k_pull2, dim3((unsigned)((c->G.plane / 2 + 255) / 256), (unsigned)c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
+    else if (which == 4 && c->G.zwrap && c->G.pitch == c->G.nx) hipLaunchKernelGGL(k_pull_rows, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
     else if (which == 2) HIP_TRY(hipMemcpyAsync(c->S[1 - c->cur], c->S[c->cur], sbytes, hipMemcpyDeviceToDevice, c->stream));
     else return fail("unknown diagnostic kernel %d", which);
   }

@@ -34,9 +34,9 @@ __global__ void __launch_bounds__(256) k_moments(const double* __restrict__ rho,
   const int p = p0 + (int)blockIdx.y;
   double v[kNMom];
   for (int k = 0; k < kNMom; ++k) v[k] = 0.;
-  if (s_ < G.plane) {
-    const int y = (int)(s_ / G.nx);
-    const int x = (int)(s_ - (long long)y * G.nx);
+  const int y = (int)(s_ / G.pitch);
+  const int x = (int)(s_ - (long long)y * G.pitch);
+  if (s_ < G.plane && x < G.nx) {
     const int z = G.z0 + (p - G.H);
     const double r = rho[(long long)p * G.plane + s_];
     double w = r;
@@ -57,9 +57,9 @@ __global__ void __launch_bounds__(256) k_tanhfit(const double* __restrict__ rho,
   const int p = p0 + (int)blockIdx.y;
   double v[kNFit];
   for (int k = 0; k < kNFit; ++k) v[k] = 0.;
-  if (s_ < G.plane) {
-    const int y = (int)(s_ / G.nx);
-    const int x = (int)(s_ - (long long)y * G.nx);
+  const int y = (int)(s_ / G.pitch);
+  const int x = (int)(s_ - (long long)y * G.pitch);
+  if (s_ < G.plane && x < G.nx) {
     const int z = G.z0 + (p - G.H);
     const double dx = (x + 0.5) * F.inv_n[0] - F.r0[0], dy = (y + 0.5) * F.inv_n[1] - F.r0[1], dz = (z + 0.5) * F.inv_n[2] - F.r0[2];
     const double r = sqrt(dx * dx + dy * dy + dz * dz);

@@ -98,7 +98,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   // byte offsets: a plane is < 4 GB (checked at creation), so  address = wave-uniform base + 32-bit lane
   // offset  and the loads/stores use the scalar-base addressing form (no 64-bit per-lane address math)
   const unsigned xo[3] = { (unsigned)wrapx(x - 1) * 8u, (unsigned)x * 8u, (unsigned)wrapx(x + 1) * 8u };
-  const unsigned yo[3] = { (unsigned)(wrapy(y - 1) * G.nx) * 8u, (unsigned)(y * G.nx) * 8u, (unsigned)(wrapy(y + 1) * G.nx) * 8u };
+  const unsigned yo[3] = { (unsigned)(wrapy(y - 1) * G.pitch) * 8u, (unsigned)(y * G.pitch) * 8u, (unsigned)(wrapy(y + 1) * G.pitch) * 8u };
   auto ld = [](const double* __restrict__ base, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff); };
   auto st = [](double* __restrict__ base, unsigned boff, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v; };
   // ---- ring half-task of this thread: lanes 0..nper-1 of every wave; the lower half of the waves sums
@@ -121,7 +121,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   const int hx = wrapx(x0 + hlx - 1);            // in [-1, nx]: one wrap suffices
   const int hy = wrapy(y0 + hly - 1);
   const unsigned hxo[3] = { (unsigned)wrapx(hx - 1) * 8u, (unsigned)hx * 8u, (unsigned)wrapx(hx + 1) * 8u };
-  const unsigned hyo[3] = { (unsigned)(wrapy(hy - 1) * G.nx) * 8u, (unsigned)(hy * G.nx) * 8u, (unsigned)(wrapy(hy + 1) * G.nx) * 8u };
+  const unsigned hyo[3] = { (unsigned)(wrapy(hy - 1) * G.pitch) * 8u, (unsigned)(hy * G.pitch) * 8u, (unsigned)(wrapy(hy + 1) * G.pitch) * 8u };
 
   const int lown = (ty + 1) * LW + (tx + 1);
   const int lhalo = hly * LW + hlx;
@@ -251,10 +251,10 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
       const double* __restrict__ nb_f = nullptr; const double* __restrict__ nb_g = nullptr;
       long long nvol = 0; unsigned no = 0;
       if (MODE == 2) {
-        nvol = (long long)(G.nzs - 2 * G.H) * G.plane;
-        nb_f = injf + (long long)(pc - G.H) * G.plane;
-        nb_g = injg + (long long)(pc - G.H) * G.plane;
-        no = yo[1] + xo[1];
+        nvol = (long long)(G.nzs - 2 * G.H) * G.dplane;          // injected arrays are dense
+        nb_f = injf + (long long)(pc - G.H) * G.dplane;
+        nb_g = injg + (long long)(pc - G.H) * G.dplane;
+        no = (unsigned)(y * G.nx + x) * 8u;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { fn3[k] = ld(nb_f + (1 + k) * nvol, no); gn3[k] = ld(nb_g + (1 + k) * nvol, no); }
       } else if (MODE == 1) {

@@ -18,8 +18,10 @@ struct Geo {
   int H;               // halo planes per side
   int z0;              // global z of storage plane H
   int nz;              // global nz
-  long long plane;     // nx*ny
-  long long vol;       // nzs*plane = component stride
+  int pitch;           // row stride of the resident arrays in elements: nx rounded up to 16 (128-byte rows)
+  long long plane;     // pitch*ny: plane stride of the resident arrays (S, rho, phi)
+  long long dplane;    // nx*ny: plane stride of dense arrays (observable outputs, injected noise, host tables)
+  long long vol;       // nzs*plane + pad = component stride
 };
 
 // compile-time velocity tables for fully unrolled loops
@@ -48,7 +50,7 @@ __device__ __forceinline__ void site_index(const Geo& G, int x, int y, int p, Si
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) I.row[a][b] = (long long)ps[a]*G.plane + (long long)ys[b]*G.nx;
+    for (int b = 0; b < 3; ++b) I.row[a][b] = (long long)ps[a]*G.plane + (long long)ys[b]*G.pitch;
 }
 
 // offset of the site displaced by (dx,dy,dz) in {-1,0,1}^3 (compile-time constants after unrolling)
@@ -123,7 +125,7 @@ __device__ __forceinline__ void site_offsets(const Geo& G, int x, int y, int p, 
   for (int a = 0; a < 3; ++a) {
     I.pl[a] = (long long)ps[a]*G.plane;
 #pragma unroll
-    for (int b = 0; b < 3; ++b) { I.o[a][b] = ((unsigned)(ys[a]*G.nx) + (unsigned)xs[b]) * 8u; asm volatile("" : "+v"(I.o[a][b])); }
+    for (int b = 0; b < 3; ++b) { I.o[a][b] = ((unsigned)(ys[a]*G.pitch) + (unsigned)xs[b]) * 8u; asm volatile("" : "+v"(I.o[a][b])); }
   }
 }
 __device__ __forceinline__ double ld_sb(const double* __restrict__ base, unsigned boff) {
@@ -153,8 +155,9 @@ __device__ __forceinline__ void gather_field(const double* __restrict__ fld, con
   const long long s_ = (long long)blockIdx.x*blockDim.x + threadIdx.x;  \
   if (s_ >= G.plane) return;                                            \
   const int p = p0 + (int)blockIdx.y;                                   \
-  const int y = (int)(s_ / G.nx);                                       \
-  const int x = (int)(s_ - (long long)y*G.nx);
+  const int y = (int)(s_ / G.pitch);                                    \
+  const int x = (int)(s_ - (long long)y*G.pitch);                       \
+  if (x >= G.nx) return;                                                /* row padding */
 
 // ---- pass A of the two-pass schedule: rho,phi of the streamed state (LBM_binary.H:320-330)
 __global__ void __launch_bounds__(256) k_density(const double* __restrict__ S, double* __restrict__ rho,
@@ -188,8 +191,8 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
   unsigned o = I.o[1][1];
   // noise: the momentum modes first (the projection needs them), each fluid's other modes right before
   // its relaxation; every fluid is stored as soon as it is collided -- keeps the live set small
-  const long long nvol = (long long)(G.nzs - 2*G.H)*G.plane;          // injected arrays: [a][p-H][y][x]
-  const long long no = (long long)(p - G.H)*G.plane + (long long)y*G.nx + x;
+  const long long nvol = (long long)(G.nzs - 2*G.H)*G.dplane;         // injected arrays, dense: [a][p-H][y][x]
+  const long long no = (long long)(p - G.H)*G.dplane + (long long)y*G.nx + x;
   double fn3[3] = {0., 0., 0.}, gn3[3] = {0., 0., 0.};
   NoiseAmp NA; float n3 = 0.f; uint64_t site = 0;
   if (INJECT) {
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(256) k_init(double* __restrict__ S, const doub
   BFLBM_SITE_FROM_BLOCK();
   const int xm = (x == 0) ? G.nx - 1 : x - 1, xp = (x == G.nx - 1) ? 0 : x + 1;
   const int ym = (y == 0) ? G.ny - 1 : y - 1, yp = (y == G.ny - 1) ? 0 : y + 1;
-  const long long o = (long long)p*G.plane + (long long)y*G.nx + x;
+  const long long o = (long long)p*G.plane + (long long)y*G.pitch + x;
   const double w0 = 1./3., w1 = 1./18., w2 = 1./36.;
 #pragma unroll
   for (int i = 0; i < Q; ++i) {
@@ -339,7 +342,7 @@ __global__ void __launch_bounds__(256) k_init(double* __restrict__ S, const doub
       else {
         const int xx = Vel::cx[i] > 0 ? xp : (Vel::cx[i] < 0 ? xm : x);
         const int yy = Vel::cy[i] > 0 ? yp : (Vel::cy[i] < 0 ? ym : y);
-        r = rho_ext[(long long)pe*G.plane + (long long)yy*G.nx + xx];
+        r = rho_ext[(long long)pe*G.dplane + (long long)yy*G.nx + xx];
       }
       ph = rho_t - r;
     }
@@ -360,8 +363,8 @@ __global__ void __launch_bounds__(256) k_observe(const double* __restrict__ S, c
   SiteIdx I; site_index(G, x, y, p, I);
   double fs[Q], gs[Q];
   pull_site(S, G, I, fs, gs);
-  const long long ovol = (long long)(G.nzs - 2*G.H)*G.plane;
-  const long long oo = (long long)(p - G.H)*G.plane + (long long)y*G.nx + x;
+  const long long ovol = (long long)(G.nzs - 2*G.H)*G.dplane;         // dense output
+  const long long oo = (long long)(p - G.H)*G.dplane + (long long)y*G.nx + x;
   const double r = d_density(fs), ph = d_density(gs);
   if (WHAT == 0) {
     double mf[Q], mg[Q];
@@ -438,9 +441,9 @@ __global__ void __launch_bounds__(256) k_reduce(const double* __restrict__ rho, 
   const long long s_ = (long long)blockIdx.x*blockDim.x + threadIdx.x;
   const int p = p0 + (int)blockIdx.y;
   double v[5] = {0., 0., 0., 0., 0.};
-  if (s_ < G.plane) {
-    const int y = (int)(s_ / G.nx);
-    const int x = (int)(s_ - (long long)y*G.nx);
+  const int y = (int)(s_ / G.pitch);
+  const int x = (int)(s_ - (long long)y*G.pitch);
+  if (s_ < G.plane && x < G.nx) {
     const long long o = (long long)p*G.plane + s_;
     const double r = rho[o];
     int gz = G.z0 + (p - G.H);

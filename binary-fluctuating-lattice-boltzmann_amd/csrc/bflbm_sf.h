@@ -185,7 +185,7 @@ int bflbm_sf_accumulate(bflbm_sf* s, int lb_hydrovars, int reset) {
   if (lb_hydrovars) hipLaunchKernelGGL((k_observe<0>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, fields, c->G, c->dp, own_lo(c), idx, BFLBM_NHYDROBAR, inj, Rf);
   else              hipLaunchKernelGGL((k_observe<2>), g, b, 0, c->stream, c->S[c->cur], c->rho, c->phi, c->injf, c->injg, fields, c->G, c->dp, own_lo(c), idx, s->nvar_fields, inj, Rf);
   HIP_TRY(hipGetLastError());
-  const long long n = (long long)c->nzl * c->G.plane;
+  const long long n = (long long)c->nzl * c->G.dplane;
   for (size_t v = 0; v < s->vars.size(); ++v)
     if (g_fft.exec_d2z(s->plan, fields + (long long)s->vars[v] * n, (hipfftDoubleComplex*)(s->hat + (long long)v * s->nk)) != HIPFFT_SUCCESS)
       return fail("hipfftExecD2Z failed");
@@ -210,7 +210,7 @@ int bflbm_sf_get(bflbm_sf* s, int what, int zero_avg, double* dst) {
   bflbm_ctx* c = s->c;
   if (c->step_open) return fail("structure factor requested inside an open step");
   HIP_TRY(hipSetDevice(c->dom.device));
-  const long long n = (long long)c->nzl * c->G.plane;
+  const long long n = (long long)c->nzl * c->G.dplane;
   double* out = c->S[1 - c->cur];                    // 38 component volumes of scratch >= 32 pairs
   dim3 g((unsigned)((n + 255) / 256), (unsigned)s->pairs.n);
   hipLaunchKernelGGL(k_sf_expand, g, dim3(256), 0, c->stream, s->acc, out, c->G.nx, c->G.ny, c->G.nz,

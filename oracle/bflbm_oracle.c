@@ -343,9 +343,12 @@ static void thermal_noise_impl(const orc_params* p, int nx, int ny, int nz, int 
     int gz = (z + gz0) % gnz; if (gz < 0) gz += gnz;
     double rho, phi, rhot;
     if (ref) {
-      int x_shift = x - (int)pos_com_relative[0];     /* static_cast<int>: truncation, :94-96 */
-      int y_shift = y - (int)pos_com_relative[1];
-      int z_shift = gz - (int)pos_com_relative[2];
+      /* static_cast<int>: truncation, :94-96.  The reference then wraps ONCE (:98-103), which is in range
+       * only for |shift| < n; the shift is therefore reduced modulo n first (no change for |shift| < n,
+       * where the reference is defined) so that no centre of mass can index outside the fields. */
+      int x_shift = x - (int)fmod(trunc(pos_com_relative[0]), (double)nx);
+      int y_shift = y - (int)fmod(trunc(pos_com_relative[1]), (double)ny);
+      int z_shift = gz - (int)fmod(trunc(pos_com_relative[2]), (double)gnz);
       if (x_shift < 0) x_shift += nx;                 /* :98-103 */
       if (x_shift > nx-1) x_shift -= nx;
       if (y_shift < 0) y_shift += ny;

@@ -137,3 +137,43 @@ def test_slab_without_global_com_fails_loudly(pkg):
     with pytest.raises(pkg.BflbmError, match="bflbm_set_com"):
         e.step_boundary()
     e.close()
+
+
+def test_shift_larger_than_the_lattice_is_periodic(pkg, ob):
+    """The reference wraps the shifted index once (LBM_binary.H:98-103), which is only in range for
+    |COM - com_ref| < n.  Here the shift trunc(COM - com_ref) is reduced modulo the lattice first (identical
+    below n), so the cell read is (x - trunc(rel)) mod n: a reference centre of mass several lattices away --
+    on the same side, truncation being toward zero -- gives the same noise as the near one, on the GPU and in
+    the oracle, instead of an out-of-range read (tests/test_oracle_pins.py has the sign-flipping cases)."""
+    nx, ny, nz = N
+    tmp = ob.OracleLattice(nx, ny, nz, ob.default_params(**PAR))
+    tmp.init_droplet(0.3)
+    rho, phi, rhot = _ref_fields(N)
+    near = tmp.com() - np.array([2.6, -1.4, 3.3])
+    far = near - np.array([3 * nx, -2 * ny, 5 * nz])           # shifts (38, -21, 73) on a 12 x 10 x 14 lattice
+    res = []
+    for com_ref in (near, far):
+        lbm = pkg.BinaryLBM(nx, ny, nz, params=pkg.default_params(**PAR))
+        orc = ob.OracleLattice(nx, ny, nz, ob.default_params(**PAR))
+        lbm.set_ref_state(rho, phi, rhot, com_ref); orc.set_ref_state(rho, phi, rhot, com_ref)
+        lbm.LBM_init(tmp.f, tmp.g); orc.init_from(tmp.f, tmp.g)
+        for _ in range(2):
+            lbm.LBM_timestep(1); orc.timestep()
+        _same(lbm, orc)
+        res.append(lbm.populations()[0])
+        lbm.close()
+    assert np.array_equal(res[0], res[1])
+
+
+def test_fluid_without_mass_fails_loudly(pkg):
+    """No fluid f at all: its centre of mass is 0/0.  The lookup must not be attempted with that."""
+    nx, ny, nz = N
+    lbm = pkg.BinaryLBM(nx, ny, nz, params=pkg.default_params(**PAR))
+    lbm.set_ref_state(*_ref_fields(N), com_ref=(6.0, 5.0, 6.0))
+    f0 = np.zeros((19, nz, ny, nx)); g0 = np.full((19, nz, ny, nx), 1.0 / 19)
+    lbm.upload(f0, g0); lbm.commit_upload()
+    with pytest.raises(pkg.BflbmError, match="not finite"):
+        lbm.LBM_timestep(1)
+    with pytest.raises(pkg.BflbmError, match="not finite"):
+        lbm.set_com((float("nan"), 0.0, 0.0))
+    lbm.close()

@@ -315,3 +315,35 @@ def test_surface_tension_notebook_system0_on_the_oracle(ob):
     want = np.array([0.015052155677499688, 3.507447510454257, 3.0222255117146184, -0.003077451215475287])
     assert np.all(np.abs(got - want) <= 1e-13 * np.abs(want))
     assert list(got) == [0.015052155677499774, 3.5074475104542557, 3.022225511714613, -0.0030774512154752736]
+
+
+def test_ref_state_shift_beyond_the_lattice_stays_in_range(ob):
+    """A relative centre of mass of several lattice lengths (or a garbage one from a fluid with almost no mass)
+    must not index outside the reference fields: the shift trunc(COM - com_ref) is reduced modulo n before the
+    reference's single wrap (LBM_binary.H:98-103 is only in range for |shift| < n), i.e. the cell read is
+    (x - trunc(rel)) mod n, what an unbounded periodic field would give.  Truncation is toward zero like the
+    reference's static_cast<int>, so the shift depends on the SIGN of rel too: trunc(-53.4) = -53 = 3 (mod 8),
+    not 2 = trunc(2.6).  Found with a 70x9x4 lattice whose 'droplet' does not exist: COM = (-241, 190, 101) ->
+    out-of-bounds read."""
+    n = (8, 6, 10)
+    par = dict(kBT=1e-5, alpha0=2.0)
+    a = ob.OracleLattice(*n, ob.default_params(**par))
+    a.init_droplet(0.3)
+    fld = 0.5 + np.random.default_rng(1).random(a.hbar[0].shape)
+
+    def noise_for(rel):
+        b = ob.OracleLattice(*n, ob.default_params(**par))
+        b.set_ref_state(fld, fld, 2 * fld, a.com() - np.asarray(rel, dtype=float))
+        b.init_from(a.f, a.g)                      # LBM_init: noise from COM - com_ref = rel
+        return b.fn.copy()
+
+    for rel in ([2.6 + 24, -1.4 - 12, 3.3 + 50], [2.6 - 56, -1.4 + 24, 3.3 - 30], [-274.7, 185.6, 99.6]):
+        shift = [int(np.fmod(np.trunc(r), m)) for r, m in zip(rel, n)]           # what must be applied
+        small = [s + (0.3 if s >= 0 else -0.3) for s in shift]                    # same truncation, in range
+        assert all(abs(s) < m for s, m in zip(shift, n))
+        assert np.array_equal(noise_for(rel), noise_for(small)), (rel, shift)
+    # and directly: amplitude of mode 4 at x comes from the field at (x - shift) mod n
+    rel = [2.6 - 56, -1.4 + 24, 3.3 - 30]
+    shift = [int(np.fmod(np.trunc(r), m)) for r, m in zip(rel, n)]
+    rolled = np.roll(fld, shift=(shift[2], shift[1], shift[0]), axis=(0, 1, 2))   # value at x = fld[(x - s) mod n]
+    np.testing.assert_allclose(noise_for(rel)[4] / np.sqrt(rolled), noise_for([0.3, 0.3, 0.3])[4] / np.sqrt(fld), rtol=1e-12)
