@@ -14,6 +14,7 @@
 #define BFLBM_NHYDRO_ 22
 #include "bflbm_kernels.h"
 #include "bflbm_fused.h"
+#include "bflbm_handover.h"
 
 namespace {
 
@@ -93,7 +94,9 @@ struct bflbm_ctx {
   bool own_stream = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   long long steps = 0;
-  int schedule = 2;              // 0 two-pass, 1 fused plane-marching, 2 auto (default)
+  int schedule = 2;              // 0 two-pass, 1 fused plane-marching (pulled ring), 2 auto (default), 3 fused with density hand-over
+  double* frames[2] = {nullptr, nullptr};   // schedule 3: tile-boundary density frames of S[0], S[1] (bflbm_handover.h)
+  HoSig fsig[2][2];              // [state buffer][0 interior sweep, 1 boundary pairs]: the launch that wrote the frames
   bool step_open = false;
   bool density_valid = false;   // rho/phi arrays hold the densities of the resident state
   size_t bytes = 0;
@@ -165,6 +168,24 @@ int launch_collide(bflbm_ctx* c, int pa, int pb) {
   return 0;
 }
 
+int ensure_frames(bflbm_ctx* c) {
+  if (c->frames[0]) return 0;
+  const size_t nb = handover_frame_doubles(c->G) * sizeof(double);
+  HIP_TRY(hipMalloc((void**)&c->frames[0], 2 * nb));
+  c->frames[1] = c->frames[0] + handover_frame_doubles(c->G);
+  c->bytes += 2 * nb;
+  return 0;
+}
+
+int launch_handover(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
+  if (pb <= pa) return 0;
+  if (ensure_frames(c)) return 1;
+  const int kind = pair_len > 0 ? 1 : 0;
+  return handover_launch(c->S[c->cur], c->S[1 - c->cur], c->frames[c->cur], c->frames[1 - c->cur], c->G, c->dp, pa, pb,
+                         c->steps, c->fsig[c->cur][kind], c->fsig[1 - c->cur][kind], c->stream, pair_len)
+             ? fail("hand-over launch failed: %s", hipGetErrorString(hipGetLastError())) : 0;
+}
+
 int launch_fused(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
   if (pb <= pa) return 0;
   return fused_launch(c->S[c->cur], c->S[1 - c->cur], c->injf, c->injg, c->G, c->dp, pa, pb,
@@ -176,8 +197,13 @@ int launch_fused(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
 // schedule use the vector units better (measured 4670-4810 vs 4100-4290 MLUPS at 256^3).
 inline int resolved_schedule(const bflbm_ctx* c) {
   if (ref_active(c)) return 0;                   // needs the densities and their centre of mass first
+  const bool noisy = c->dp.noise_on || c->inject;
+  // the hand-over kernel is the zero-noise kernel and needs full 64 x TY tiles with distinct neighbours
+  if (c->schedule == 3) return noisy ? 0 : (handover_ok(c->G) ? 3 : 1);
   if (c->schedule != 2) return c->schedule;
-  return (c->dp.noise_on || c->inject) ? 0 : 1;
+  // auto never picks the hand-over kernel: its producer does not fit the register file at two waves per SIMD
+  // (scratch spills: 4100-4500 MLUPS against 7050-7350 for schedule 1)
+  return noisy ? 0 : 1;
 }
 
 // the slab's own planes are [H, H+nzl)
@@ -372,6 +398,7 @@ int bflbm_destroy(bflbm_ctx* c) {
   hipSetDevice(c->dom.device);
   if (c->stream && c->own_stream) hipStreamSynchronize(c->stream);
   if (c->S[0]) hipFree(c->S[0]);                 // S[1] lives in the same allocation
+  if (c->frames[0]) hipFree(c->frames[0]);
   if (c->rho) hipFree(c->rho);
   if (c->phi) hipFree(c->phi);
   if (c->injf) hipFree(c->injf);
@@ -414,7 +441,7 @@ int bflbm_set_stream(bflbm_ctx* c, void* s, int external) {
 
 int bflbm_set_schedule(bflbm_ctx* c, int schedule) {
   if (!c) return fail("null context");
-  if (schedule < 0 || schedule > 2) return fail("unknown schedule %d", schedule);
+  if (schedule < 0 || schedule > 3) return fail("unknown schedule %d", schedule);
   c->schedule = schedule;
   return 0;
 }
@@ -428,6 +455,7 @@ static int run_init(bflbm_ctx* c, int mode, const double* rho_ext_host, size_t n
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->steps = 0; c->density_valid = false; c->step_open = false; c->com_valid = false;
+  for (auto& b : c->fsig) for (auto& sg : b) sg = HoSig();     // the hand-over frames describe another state
   c->ref_kind = (mode == 0) ? 2 : 1;             // thermal_noise gets the absolute COM (:623-625) or zero (:690, :739)
   c->ref_kind_step = 0;
   return 0;
@@ -516,6 +544,7 @@ int bflbm_commit_upload(bflbm_ctx* c, int reset) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (reset) c->steps = 0;
   c->density_valid = false; c->step_open = false; c->com_valid = false;
+  for (auto& b : c->fsig) for (auto& sg : b) sg = HoSig();
   c->ref_kind = 0; c->ref_kind_step = c->steps;  // LBM_init: COM relative to com_ref (:651-654)
   return 0;
 }
@@ -542,7 +571,13 @@ int bflbm_step_boundary(bflbm_ctx* c) {
   c->step_open = true;
   const int lo = own_lo(c), hi = own_hi(c);
   if (c->G.zwrap) return 0;                      // single slab: everything is "interior"
-  if (resolved_schedule(c) == 1) {
+  const int sch = resolved_schedule(c);
+  if (sch == 3) {
+    if (hi - lo > 4) return launch_handover(c, lo, hi, 2);
+    if (launch_handover(c, lo, lo + 2, 2)) return 1;
+    return launch_handover(c, hi - 2, hi, 2);
+  }
+  if (sch == 1) {
     if (hi - lo > 4) return launch_fused(c, lo, hi, 2);      // both boundary plane pairs in one launch
     if (launch_fused(c, lo, lo + 2)) return 1;
     return launch_fused(c, hi - 2, hi);
@@ -558,7 +593,9 @@ int bflbm_step_interior(bflbm_ctx* c) {
   HIP_TRY(hipSetDevice(c->dom.device));
   const int lo = own_lo(c), hi = own_hi(c);
   const int a = c->G.zwrap ? lo : lo + 2, b = c->G.zwrap ? hi : hi - 2;
-  if (resolved_schedule(c) == 1) return launch_fused(c, a, b);
+  const int sch = resolved_schedule(c);
+  if (sch == 3) return launch_handover(c, a, b);
+  if (sch == 1) return launch_fused(c, a, b);
   if (ensure_density(c)) return 1;
   return launch_collide(c, a, b);
 }

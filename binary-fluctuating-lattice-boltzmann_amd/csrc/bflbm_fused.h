@@ -32,6 +32,7 @@ struct FusedGrid {
   int ncols;           // ntx*nty
   int total;           // ncols*nchunks workgroups
   int per_xcd;         // ceil(total/8)
+  int sx;              // strip width (tiles in x) of the column order, see fused_map
   unsigned long long* dbg;   // BFLBM_STAMP diagnostic builds only: per-workgroup phase cycle sums
 };
 
@@ -44,9 +45,19 @@ __device__ __forceinline__ bool fused_map(const FusedGrid& F, int b, int& col, i
   if (j >= F.per_xcd || w >= F.total) return false;
   // inside the list: chunk-major over groups of columns so that concurrently resident workgroups
   // of one XCD are neighbouring columns of the same chunk
-  col = w % F.ncols;
   chunk = w / F.ncols;
-  // interleave: consecutive w within an XCD walk columns first
+  const int c = w % F.ncols;
+  // column order inside the list: strips of F.sx tiles in x, tile rows (y) fastest inside a strip, so that the
+  // workgroups resident together on an XCD cover a compact block whose inner ring rows are shared through L2
+  // (sx == ntx is row-major order: a band of whole tile rows)
+  if (F.sx >= F.ntx) { col = c; }
+  else {
+    const int per_strip = F.sx * F.nty;
+    const int strip = c / per_strip, r = c - strip * per_strip;
+    const int w_strip = min(F.sx, F.ntx - strip * F.sx);       // last strip may be narrower
+    const int tiy = r / w_strip, tix = strip * F.sx + (r - tiy * w_strip);
+    col = tiy * F.ntx + tix;
+  }
   return true;
 }
 
@@ -72,7 +83,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   constexpr int LW = TX + 2;                     // LDS row length
   constexpr int LSZ = (TX + 2) * (TY + 2);
   constexpr int NW = TX * TY / 64;
-  static_assert(NW % 2 == 0 && (2 * (TX + 2) + 2 * TY) <= 64 * (NW / 2), "ring tasks of one fluid must fit one per lane of half the waves");
+  static_assert((BFLBM_ABL & 1) || (NW % 2 == 0 && (2 * (TX + 2) + 2 * TY) <= 64 * (NW / 2)), "ring tasks of one fluid must fit one per lane of half the waves");
   __shared__ double rp[4][2][LSZ];               // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
   __shared__ double gl[Q][TX * TY];              // g populations of the previous plane
 #ifdef BFLBM_NOISE_EARLY
@@ -399,6 +410,7 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   if (pair_len > 0 && np > 2 * pair_len) { F.lz = pair_len; F.nchunks = 2; F.cstride = np - pair_len; }
   F.total = F.ncols * F.nchunks;
   F.per_xcd = (F.total + 7) / 8;
+  { static const int sx_env = [] { const char* e = getenv("BFLBM_MAP_SX"); return e ? atoi(e) : 0; }(); F.sx = sx_env > 0 ? sx_env : std::min(F.ntx, 4); }   // strips of 4 tiles: +2 % at 512^3 (ntx = 8), identical at 256^3
   F.dbg = nullptr;
 #ifdef BFLBM_STAMP
   { static unsigned long long* dbuf = nullptr; if (!dbuf) hipMalloc(&dbuf, 8192 * 16 * 8 * sizeof(unsigned long long)); F.dbg = dbuf; g_stamp_buf = dbuf; g_stamp_n = F.per_xcd * 8 * (TX * TY / 64); }

@@ -1,0 +1,487 @@
+// bflbm_handover.h -- fused plane-marching collide-and-stream kernel with a cross-step hand-over of the
+// tile-boundary densities (schedule 3).
+//
+// The plane march of bflbm_fused.h needs rho,phi of the streamed state on a one-site ring around each
+// workgroup's tile (gradient stencil, LBM_binary.H:134-150 applied to the densities of :315-330).  There
+// the ring is pulled: 19 loads per ring site and fluid to produce one number, lines that belong to the
+// neighbouring tiles (measured: 1.33x-1.6x the algorithmic read bytes, profiles/r01_*).  Here the ring
+// densities of step t+1 are handed over from step t instead:
+//
+//   rho_{t+1}(r) = sum_i f*_i(r - c_i)           (f* = post-collision populations of step t)
+//
+// While the 19 outputs of a site are in registers the producing workgroup sorts them by destination:
+//   x  wave shifts (DPP wave_shr/wave_shl, a tile row is one 64-lane wave)       -> 9 buckets (dy,dz)
+//   z  a two-stage register/LDS pipeline along the march                          -> 3 sums (dy)
+//   y  finished sums of the row next to an edge row cross through LDS
+// and writes per tile, plane and fluid a FRAME of partial sums over the sources INSIDE the tile:
+//   E  for its own edge sites      (2*64 + 2*(TY-2) values)   -- what the neighbours are missing
+//   O  for the ring sites outside  (2*64 + 2*(TY+2) values)   -- what it contributes to the neighbours
+// Step t+1 forms the ring density of a site as  E(owner tile) + O(own tile) [+ O of the two other tiles
+// at the 12 sites next to a tile corner]: 2-4 loads instead of 19.  Frame traffic: 2*FR/(64*TY) values per
+// site and fluid each way (64x4 tiles: +5.7 % of 608 B/site).
+//
+// The tile's OWN densities are still summed from the pulled populations in the reference's order.  The ring
+// densities are sums of the same 19 numbers in a different, fixed order: deterministic, equal to the
+// reference's to an ulp, not bit-identical; they only enter the gradient of the tile's edge sites.  The
+// schedule is therefore held to the north-star tolerance (rho,phi rel 1e-12, u abs 1e-12 cs) and the two
+// bit-exact schedules (0 two-pass, 1 fused with pulled ring) remain the cross-check.
+//
+// Frames of the first and last plane of a chunk would need sources of the neighbouring chunk: those planes
+// (and every plane of the first step after an init/upload) use the pulled ring.  Requires full tiles
+// (nx % 64 == 0, ny % TY == 0) and at least two tiles per direction; the host falls back to schedule 1 otherwise.
+#ifndef BFLBM_HANDOVER_H_
+#define BFLBM_HANDOVER_H_
+
+#include "bflbm_fused.h"
+
+template <int TY> struct HoLayout {
+  static constexpr int TX = 64;
+  // slots of one fluid's frame (doubles)
+  static constexpr int EB = 0, ET = TX, EL = 2 * TX, ER = EL + (TY - 2);
+  static constexpr int OB = ER + (TY - 2), OT = OB + TX, OL = OT + TX, OR_ = OL + (TY + 2);
+  static constexpr int FR = OR_ + (TY + 2);            // 4*TX + 4*TY: 272 (TY=4), 288 (TY=8) -- whole 128-byte lines
+  static constexpr int REC = 2 * FR;                   // both fluids
+};
+
+struct HoGrid {
+  const double* fin;     // frames of the state being read   [plane][tile][fluid][FR]
+  double* fout;          // frames of the state being written
+  long long fplane;      // doubles per plane = ntiles * REC
+  int use_frames;        // fin holds frames written by the same launch geometry one step earlier
+};
+
+// destination slot of lattice site (lx,ly), given relative to a tile's origin, in that tile's frame; -1: none
+template <int TY>
+__device__ __forceinline__ int ho_frame_slot(int lx, int ly) {
+  using L = HoLayout<TY>;
+  constexpr int TX = L::TX;
+  if (lx >= 0 && lx < TX && ly >= 0 && ly < TY) {
+    if (ly == 0) return L::EB + lx;
+    if (ly == TY - 1) return L::ET + lx;
+    if (lx == 0) return L::EL + ly - 1;
+    if (lx == TX - 1) return L::ER + ly - 1;
+    return -1;
+  }
+  if (lx >= 0 && lx < TX) {
+    if (ly == -1) return L::OB + lx;
+    if (ly == TY) return L::OT + lx;
+    return -1;
+  }
+  if (ly >= -1 && ly <= TY) {
+    if (lx == -1) return L::OL + ly + 1;
+    if (lx == TX) return L::OR_ + ly + 1;
+  }
+  return -1;
+}
+// coordinate g relative to origin o on a periodic axis of length n, mapped to [-1, T] or a large value
+__device__ __forceinline__ int ho_rel(int g, int o, int n, int T) {
+  int d = g - o;
+  if (d < 0) d += n;
+  if (d <= T) return d;
+  if (d == n - 1) return -1;
+  return 1 << 20;
+}
+
+__device__ __forceinline__ double ho_shr(double v) {   // value of lane-1 (travelling +x), 0 in lane 0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ho_shl(double v) {   // value of lane+1 (travelling -x), 0 in lane 63
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int TY>
+__global__ void __launch_bounds__(64 * TY, 2)
+k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParams P, FusedGrid F, HoGrid Hg) {
+  using L = HoLayout<TY>;
+  constexpr int TX = 64, NT = TX * TY, NW = TY;
+  constexpr int LW = TX + 2, LSZ = (TX + 2) * (TY + 2);
+  constexpr int NRING = 2 * (TX + 2) + 2 * TY;
+  constexpr int NPER = (NRING + NW - 1) / NW;          // ring sites per wave (frame path)
+  static_assert(TY >= 4 && NPER <= 64 && 8 * TY <= 64, "tile shape");
+  __shared__ double rp[4][2][LSZ];                     // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
+  __shared__ double gl[Q][NT];                         // g populations of the previous plane
+  __shared__ double exch[2][2][2][2][TX];              // [buf][fluid][side][0 edge row's own sum, 1 sum handed over by the row next to it][lane]
+  __shared__ double accs[2][2][2][TX];                 // [stage][fluid][side][lane] z pipeline of the edge rows' own sums
+  __shared__ double colacc[2][2][2][TY][6];            // [stage][fluid][side][row][kind] z pipeline of the column lanes
+  __shared__ double colfin[2][2][2][TY][6];            // [buf][fluid][side][row][kind] finished column sums
+
+  int col, chunk;
+  if (!fused_map(F, (int)blockIdx.x, col, chunk)) return;
+  const int tix = col % F.ntx, tiy = col / F.ntx;
+  const int x0 = tix * TX, y0 = tiy * TY;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);   // a wave is a tile row
+  const int tx = lane;
+  auto wrapx = [&](int v) { return v < 0 ? v + G.nx : (v >= G.nx ? v - G.nx : v); };
+  auto wrapy = [&](int v) { return v < 0 ? v + G.ny : (v >= G.ny ? v - G.ny : v); };
+  auto ld = [](const double* __restrict__ base, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff); };
+  auto st = [](double* __restrict__ base, unsigned boff, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v; };
+
+  const int x = x0 + tx, y = y0 + ty;
+  const unsigned xo[3] = { (unsigned)wrapx(x - 1) * 8u, (unsigned)x * 8u, (unsigned)wrapx(x + 1) * 8u };
+  const unsigned yo[3] = { (unsigned)(wrapy(y - 1) * G.pitch) * 8u, (unsigned)(y * G.pitch) * 8u, (unsigned)(wrapy(y + 1) * G.pitch) * 8u };
+  const int lown = (ty + 1) * LW + (tx + 1);
+
+  // ---- roles of this thread in the frame production
+  const bool row_down = ty < 2, row_up = ty >= TY - 2;       // rows whose -y / +y travelling sums are needed
+  const bool row_kind = row_down || row_up;                  // wave-uniform
+  const bool edge_row = (ty == 0) || (ty == TY - 1);
+  const bool is_edge = (tid < TX) || (tid >= NT - TX);       // the same as a lane predicate (keeps the producer free of uniform branches)
+  const int side_y = row_down ? 0 : 1;
+  const bool col_lane = (tx == 0) || (tx == TX - 1);
+  const int side_x = (tx == 0) ? 0 : 1;
+  const unsigned tile_rec = (unsigned)((tiy * F.ntx + tix) * L::REC) * 8u;     // byte offset of this tile's frame in a plane
+  // ---- ring site of this thread when the ring comes from frames: lanes 0..NPER-1 of every wave, both fluids
+  const int rtask = ty * NPER + lane;
+  const bool has_rtask = lane < NPER && rtask < NRING;
+  int hlx = 0, hly = 0;
+  if (has_rtask) {
+    const int r = rtask;
+    if (r < TX + 2) { hlx = r; hly = 0; }
+    else if (r < 2 * (TX + 2)) { hlx = r - (TX + 2); hly = TY + 1; }
+    else if (r < 2 * (TX + 2) + TY) { hlx = 0; hly = r - 2 * (TX + 2) + 1; }
+    else { hlx = TX + 1; hly = r - 2 * (TX + 2) - TY + 1; }
+  }
+  const int lhalo = hly * LW + hlx;
+  // the frames that hold a piece of this ring site: the owner's E and the O of every other tile around it
+  unsigned fo[4] = {0u, 0u, 0u, 0u};
+  int nfo = 0;
+  if (has_rtask) {
+    const int gx = wrapx(x0 + hlx - 1), gy = wrapy(y0 + hly - 1);
+    for (int dty = -1; dty <= 1; ++dty) {
+      if (dty == 1 && F.nty == 2) continue;                  // the same tile as dty = -1
+      for (int dtx = -1; dtx <= 1; ++dtx) {
+        if (dtx == 1 && F.ntx == 2) continue;
+        int ux = tix + dtx, uy = tiy + dty;
+        ux = ux < 0 ? ux + F.ntx : (ux >= F.ntx ? ux - F.ntx : ux);
+        uy = uy < 0 ? uy + F.nty : (uy >= F.nty ? uy - F.nty : uy);
+        const int slot = ho_frame_slot<TY>(ho_rel(gx, ux * TX, G.nx, TX), ho_rel(gy, uy * TY, G.ny, TY));
+        if (slot >= 0 && nfo < 4) { fo[nfo] = (unsigned)((uy * F.ntx + ux) * L::REC + slot) * 8u; ++nfo; }
+      }
+    }
+  }
+
+  const int qa = F.pa + chunk * F.cstride;
+  const int qb = min(F.pb, qa + F.lz);
+  auto wrapp = [&](int q) {
+    if (!G.zwrap) return q;
+    const int m = q % G.nzs;
+    return m < 0 ? m + G.nzs : m;
+  };
+  // planes whose frames are complete: all three source planes collided by this workgroup
+  const int fa = qa + 1, fb = qb - 2;                        // [fa, fb]
+
+  double pf[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) pf[i] = 0.;
+  double anb[2][2] = {{0., 0.}, {0., 0.}};                   // [fluid][stage] z pipeline of the row's travelling sum
+
+  // finish the frames of plane tpf from what the previous march position left in LDS (after a barrier)
+  auto finish = [&](int tpf, int rb) {
+    if (tpf < fa || tpf > fb) return;
+    double* __restrict__ fp = Hg.fout + (long long)tpf * Hg.fplane;
+    if (edge_row) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const double e = exch[rb][k][side_y][0][lane] + exch[rb][k][side_y][1][lane];
+        st(fp, tile_rec + (unsigned)(k * L::FR + (side_y ? L::ET : L::EB) + lane) * 8u, e);
+      }
+    }
+    if (ty == 0 && lane < 8 * TY) {
+      const int k = lane / (4 * TY), rem = lane % (4 * TY), sd = rem / (2 * TY), u = rem % (2 * TY);
+      double v; int slot;
+      if (u < TY - 2) {                                        // own edge site of the column, rows 1..TY-2
+        const int row = u + 1;
+        v = colfin[rb][k][sd][row][0] + colfin[rb][k][sd][row - 1][1] + colfin[rb][k][sd][row + 1][2];
+        slot = (sd ? L::ER : L::EL) + row - 1;
+      } else {                                                 // ring site beside the column, rows -1..TY
+        const int row = u - (TY - 2) - 1;
+        v = 0.;
+        if (row >= 0 && row < TY) v = colfin[rb][k][sd][row][3];
+        if (row - 1 >= 0 && row - 1 < TY) v += colfin[rb][k][sd][row - 1][4];
+        if (row + 1 >= 0 && row + 1 < TY) v += colfin[rb][k][sd][row + 1][5];
+        slot = (sd ? L::OR_ : L::OL) + row + 1;
+      }
+      st(fp, tile_rec + (unsigned)(k * L::FR + slot) * 8u, v);
+    }
+  };
+
+  int it = 0;
+  for (int q = qa - 1; q <= qb; ++q, ++it) {
+    const int slot = it & 3;
+    const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
+                                         S + (long long)wrapp(q + 1) * G.plane };
+    // 1. pull plane q
+    double cf[Q], cg[Q];
+    {
+      unsigned oo[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) { oo[a][b2] = yo[a] + xo[b2]; asm volatile("" : "+v"(oo[a][b2])); }
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
+        const unsigned o = oo[1 - Vel::cy[i]][1 - Vel::cx[i]];
+        cf[i] = ld(b, o);
+        cg[i] = ld(b + (long long)Q * G.vol, o);
+      }
+    }
+    const bool ring_from_frames = Hg.use_frames && q >= fa && q <= fb;       // uniform over the workgroup
+    double zero = 0.0;
+    asm volatile("" : "+v"(zero));
+    auto density = [&](const double (&fs)[Q]) { double r = zero;
+#pragma unroll
+      for (int i = 0; i < Q; ++i) r += fs[i];
+      return r; };
+    if (ring_from_frames) {
+      double hv[2][4];
+      if (has_rtask) {
+        const double* __restrict__ fp = Hg.fin + (long long)wrapp(q) * Hg.fplane;   // q is in [fa, fb]; wrapp only keeps ablation builds in range
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned o = fo[j];
+          asm volatile("" : "+v"(o));
+          if (j < 2 || j < nfo) { hv[0][j] = ld(fp, o); hv[1][j] = ld(fp + L::FR, o); }
+          else { hv[0][j] = 0.; hv[1][j] = 0.; }
+        }
+      }
+      rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg);
+      if (has_rtask) {
+        double r0 = hv[0][0] + hv[0][1], r1 = hv[1][0] + hv[1][1];
+        if (nfo > 2) { r0 += hv[0][2]; r1 += hv[1][2]; }
+        if (nfo > 3) { r0 += hv[0][3]; r1 += hv[1][3]; }
+        rp[slot][0][lhalo] = r0; rp[slot][1][lhalo] = r1;
+      }
+    } else {
+      rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg);
+      // pulled ring (chunk-boundary planes, first step): threads 0..NRING-1 pull one ring site, fluid after
+      // fluid (wave-uniform base + 32-bit lane offset, like the own loads); a rare path, kept small
+      if (tid < NRING) {
+        const int r = tid;
+        int rx, ry;
+        if (r < TX + 2) { rx = r; ry = 0; }
+        else if (r < 2 * (TX + 2)) { rx = r - (TX + 2); ry = TY + 1; }
+        else if (r < 2 * (TX + 2) + TY) { rx = 0; ry = r - 2 * (TX + 2) + 1; }
+        else { rx = TX + 1; ry = r - 2 * (TX + 2) - TY + 1; }
+        const int hx = wrapx(x0 + rx - 1), hy = wrapy(y0 + ry - 1);
+        const unsigned hxo[3] = { (unsigned)wrapx(hx - 1) * 8u, (unsigned)hx * 8u, (unsigned)wrapx(hx + 1) * 8u };
+        const unsigned hyo[3] = { (unsigned)(wrapy(hy - 1) * G.pitch) * 8u, (unsigned)(hy * G.pitch) * 8u, (unsigned)(wrapy(hy + 1) * G.pitch) * 8u };
+        for (int fl = 0; fl < 2; ++fl) {
+          double rs = zero;
+#pragma unroll
+          for (int i = 0; i < Q; ++i) {
+            unsigned o = hyo[1 - Vel::cy[i]] + hxo[1 - Vel::cx[i]];
+            asm volatile("" : "+v"(o));
+            rs += ld(pl[1 - Vel::cz[i]] + (long long)(fl * Q + i) * G.vol, o);
+          }
+          rp[slot][fl][ry * LW + rx] = rs;
+        }
+      }
+    }
+    __syncthreads();
+    // frames of plane q-3: finished at the previous position, combined across rows now
+    finish(q - 3, (it & 1) ^ 1);
+    // 3. collide plane q-1
+    const int pc = q - 1;
+    const bool do_collide = (pc >= qa) && (pc < qb);
+    double mg[Q], jg[3];
+    if (do_collide) {
+      double pg[Q];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) pg[i] = gl[i][tid];
+      d_moments(pg, mg);
+      d_momentum(pg, jg);
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) gl[i][tid] = cg[i];
+    if (do_collide) {
+      double mf[Q], jf[3];
+      d_moments(pf, mf);
+      d_momentum(pf, jf);
+      const int sl[3] = { (it - 2) & 3, (it - 1) & 3, it & 3 };
+      const double r = rp[sl[1]][0][lown], ph = rp[sl[1]][1][lown];
+      double nb[Q], grad_rho[3], grad_phi[3];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) nb[i] = rp[sl[1 + Vel::cz[i]]][0][lown + Vel::cy[i] * LW + Vel::cx[i]];
+      d_gradient(P, nb, grad_rho);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) nb[i] = rp[sl[1 + Vel::cz[i]]][1][lown + Vel::cy[i] * LW + Vel::cx[i]];
+      d_gradient(P, nb, grad_phi);
+      const int pcw = wrapp(pc);
+      const double fn3[3] = {0., 0., 0.}, gn3[3] = {0., 0., 0.};
+      double* __restrict__ Dp = D + (long long)pcw * G.plane;
+      unsigned o = yo[1] + xo[1];
+      asm volatile("" : "+v"(o));
+      SiteHydro Hy;
+      SiteRecip R;
+      d_site_recips(P, r, ph, R);
+      d_hydrovars_j(P, jf, jg, r, ph, grad_rho, grad_phi, fn3, gn3, Hy, R);
+      double v_b[3];
+      d_barycentric(r, ph, Hy, v_b, R);
+      const int tp = pc - 1;                                   // plane whose sums become complete now
+      const bool tp_ok = tp >= fa && tp <= fb;
+      double* __restrict__ fp = Hg.fout + (long long)tp * Hg.fplane;
+      const int wb = it & 1;
+      const double zn[Q] = {0.};
+      // sorts the 19 outputs of one fluid by destination and advances the z pipelines (see the header comment)
+      // moments -> populations (same operations as d_populations, LBM_d3q19.H:167-247), issued in stages: a
+      // group of three populations that share a destination (dy,dz) is stored and folded into its x bucket
+      // before the next group is formed, so that the 19 outputs are never live together (register budget)
+      auto finish_fluid = [&](const double (&mom)[Q], const int k) {
+        double m[Q];
+        m[0]  = d_div9(mom[0])  * 0.25;   m[1]  = d_div3(mom[1])  * 0.25;   m[2]  = d_div3(mom[2])  * 0.25;
+        m[3]  = d_div3(mom[3])  * 0.25;   m[4]  = d_div3(mom[4])  * 0.125;  m[5]  = d_div3(mom[5])  * 0.0625;
+        m[6]  = mom[6]  * 0.0625;         m[7]  = mom[7]  * 0.25;           m[8]  = mom[8]  * 0.25;
+        m[9]  = mom[9]  * 0.25;           m[10] = d_div3(mom[10]) * 0.125;  m[11] = d_div3(mom[11]) * 0.125;
+        m[12] = d_div3(mom[12]) * 0.125;  m[13] = mom[13] * 0.125;          m[14] = mom[14] * 0.125;
+        m[15] = mom[15] * 0.125;          m[16] = d_div9(mom[16]) * 0.125;  m[17] = d_div3(mom[17]) * 0.0625;
+        m[18] = mom[18] * 0.0625;
+        const double mc0 = 12.*(m[0] - m[4] + m[16]);
+        const double mc1 =  2.*(m[0] - 2.*m[16]);
+        const double mc2 = m[0] + m[4] + m[16];
+        const double mx1 = 2.*(m[1] - 2.*m[10]), my1 = 2.*(m[2] - 2.*m[11]), mz1 = 2.*(m[3] - 2.*m[12]);
+        const double mx2 = m[1] + m[10] + m[13], my2 = m[2] + m[11] + m[14], mz2 = m[3] + m[12] + m[15];
+        const double mx3 = m[1] + m[10] - m[13], my3 = m[2] + m[11] - m[14], mz3 = m[3] + m[12] - m[15];
+        const double mxx1 = mc1 + 4.*(m[5] - m[17]);
+        const double myy1 = mc1 - 2.*(m[5] - m[6]) + 2.*(m[17] - m[18]);
+        const double mzz1 = mc1 - 2.*(m[5] + m[6]) + 2.*(m[17] + m[18]);
+        const double mxy2 = mc2 + (m[5] + m[6]) + (m[17] + m[18]);
+        const double mxz2 = mc2 + (m[5] - m[6]) + (m[17] - m[18]);
+        const double myz2 = mc2 - 2.*(m[5] + m[17]);
+        const double mxy = m[7], myz = m[8], mxz = m[9];
+        double* __restrict__ Dk = Dp + (long long)(k * Q) * G.vol;
+        auto put = [&](int i, double v) { st(Dk + (long long)i * G.vol, o, v); };
+        const double o0 = mc0, o1 = mxx1 + mx1, o2 = mxx1 - mx1;
+        put(0, o0); put(1, o1); put(2, o2);
+        const double x00 = o0 + ho_shr(o1) + ho_shl(o2);
+        const double o3 = myy1 + my1, o7 = mxy2 + mx2 + my3 + mxy, o10 = mxy2 - mx2 + my3 - mxy;
+        put(3, o3); put(7, o7); put(10, o10);
+        const double xp0 = o3 + ho_shr(o7) + ho_shl(o10);
+        const double o4 = myy1 - my1, o9 = mxy2 + mx2 - my3 - mxy, o8 = mxy2 - mx2 - my3 + mxy;
+        put(4, o4); put(9, o9); put(8, o8);
+        const double xm0 = o4 + ho_shr(o9) + ho_shl(o8);
+        const double o5 = mzz1 + mz1, o15 = mxz2 + mz2 + mx3 + mxz, o18 = mxz2 + mz2 - mx3 - mxz;
+        put(5, o5); put(15, o15); put(18, o18);
+        const double x0p = o5 + ho_shr(o15) + ho_shl(o18);
+        const double o6 = mzz1 - mz1, o17 = mxz2 - mz2 + mx3 - mxz, o16 = mxz2 - mz2 - mx3 + mxz;
+        put(6, o6); put(17, o17); put(16, o16);
+        const double x0m = o6 + ho_shr(o17) + ho_shl(o16);
+        const double o11 = myz2 + my2 + mz3 + myz, o12 = myz2 - my2 - mz3 + myz, o13 = myz2 + my2 - mz3 - myz, o14 = myz2 - my2 + mz3 - myz;
+        put(11, o11); put(12, o12); put(13, o13); put(14, o14);
+        // what leaves the tile in x (column lanes only; side_x picks the lane's outward direction)
+        const double oxp = side_x ? o15 : o18, ox0 = side_x ? o1 : o2, oxm = side_x ? o17 : o16, oyp = side_x ? o7 : o10, oym = side_x ? o9 : o8;
+        // travelling sum towards the nearer tile edge (rows 0,1: -y; rows TY-2,TY-1: +y): contributions to
+        // planes p+1, p, p-1 enter a two-stage pipeline, what leaves it is complete for plane p-1
+        const double np = row_down ? o14 : o11, n0 = row_down ? xm0 : xp0, nm = row_down ? o12 : o13;
+        const double fin_nb = anb[k][1] + nm;
+        anb[k][1] = anb[k][0] + n0;
+        anb[k][0] = np;
+        double hand = fin_nb;                     // rows next to an edge row hand their sum to the edge row
+        if (is_edge) {                            // (lane predicate) own sums of the edge row; its travelling sum is the ring's
+          const double fin_self = accs[1][k][side_y][lane] + x0m;
+          accs[1][k][side_y][lane] = accs[0][k][side_y][lane] + x00;
+          accs[0][k][side_y][lane] = x0p;
+          hand = fin_self;
+          if (tp_ok) st(fp, tile_rec + (unsigned)(k * L::FR + (side_y ? L::OT : L::OB) + lane) * 8u, fin_nb);
+        }
+        if (TY == 4 || row_kind) exch[wb][k][side_y][edge_row ? 0 : 1][lane] = hand;
+        if (col_lane) {
+          // kinds: 0..2 sums travelling dy = 0,+1,-1 inside the column; 3..5 what leaves the tile in x with dy = 0,+1,-1
+          const double vp[6] = { x0p, o11, o14, oxp, 0., 0. };
+          const double v0[6] = { x00, xp0, xm0, ox0, oyp, oym };
+          const double vm[6] = { x0m, o13, o12, oxm, 0., 0. };
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            colfin[wb][k][side_x][ty][j] = colacc[1][k][side_x][ty][j] + vm[j];
+            colacc[1][k][side_x][ty][j] = colacc[0][k][side_x][ty][j] + v0[j];
+            colacc[0][k][side_x][ty][j] = vp[j];
+          }
+        }
+      };
+      d_relax<false>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, zn, R.cs4);
+      finish_fluid(mf, 0);
+      d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
+      finish_fluid(mg, 1);
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) pf[i] = cf[i];
+  }
+  // the last complete plane (qb-2) was finished at the last position; combine it across rows
+  __syncthreads();
+  finish(qb - 2, (it & 1) ^ 1);
+}
+
+#ifndef BFLBM_HO_TY
+#define BFLBM_HO_TY 4
+#endif
+
+// hand-over frames need full tiles and distinct neighbour tiles
+static inline bool handover_ok(const Geo& G) {
+  constexpr int TY = BFLBM_HO_TY;
+  return (G.nx % 64 == 0) && (G.ny % TY == 0) && (G.nx / 64 >= 2) && (G.ny / TY >= 2);
+}
+static inline size_t handover_frame_doubles(const Geo& G) {
+  constexpr int TY = BFLBM_HO_TY;
+  return (size_t)(G.nx / 64) * (size_t)(G.ny / TY) * HoLayout<TY>::REC * (size_t)G.nzs;
+}
+
+struct HoSig { int pa = -1, pb = -1, lz = -1, nchunks = -1, cstride = -1; long long step = -1;
+  bool same_geometry(const HoSig& o) const { return pa == o.pa && pb == o.pb && lz == o.lz && nchunks == o.nchunks && cstride == o.cstride; } };
+
+// fin/fout: frame buffers of the state read / written.  sig_in: what wrote fin (step == steps-1 required);
+// sig_out receives this launch.  returns non-zero on launch failure
+static inline int handover_launch(const double* S, double* D, const double* fin, double* fout, const Geo& G, const DevParams& P,
+                                  int pa, int pb, long long steps, const HoSig& sig_in, HoSig& sig_out, hipStream_t stream, int pair_len = 0) {
+  constexpr int TX = 64, TY = BFLBM_HO_TY;
+  FusedGrid F;
+  F.ntx = G.nx / TX; F.nty = G.ny / TY;
+  F.ncols = F.ntx * F.nty;
+  F.pa = pa; F.pb = pb;
+  const int np = pb - pa;
+  static const int want_env = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 0; }();
+  // two 256-thread workgroups are resident per CU (LDS and registers), so a round is 2 x ncu workgroups
+  const int slots = (g_fused_ncu > 0 ? g_fused_ncu : 256) * (TY == 4 ? 2 : 1);
+  static const int min_slab_rounds = [] { const char* e = getenv("BFLBM_SLAB_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
+  const int maxchunks = std::max(1, np / 4);                     // a chunk shorter than 4 planes has no complete frame
+  int nchunks;
+  if (want_env > 0) {
+    nchunks = std::min(maxchunks, std::max(1, (want_env + F.ncols - 1) / F.ncols));
+  } else {
+    long long best = -1; nchunks = 1;
+    for (int k = 1; k <= maxchunks; ++k) {
+      const int lz = (np + k - 1) / k, chunks = (np + lz - 1) / lz;
+      if (chunks != k) continue;
+      if (G.zwrap && lz > 256 && k < maxchunks) continue;
+      const long long total = (long long)F.ncols * chunks, rounds = (total + slots - 1) / slots;
+      if (!G.zwrap && rounds < min_slab_rounds && k < maxchunks) continue;
+      const long long cost = rounds * (lz + 1);
+      if (best < 0 || cost < best) { best = cost; nchunks = k; }
+    }
+  }
+  F.lz = (np + nchunks - 1) / nchunks;
+  F.nchunks = (np + F.lz - 1) / F.lz;
+  F.cstride = F.lz;
+  if (pair_len > 0 && np > 2 * pair_len) { F.lz = pair_len; F.nchunks = 2; F.cstride = np - pair_len; }
+  F.total = F.ncols * F.nchunks;
+  F.per_xcd = (F.total + 7) / 8;
+  { static const int sx_env = [] { const char* e = getenv("BFLBM_MAP_SX"); return e ? atoi(e) : 0; }(); F.sx = sx_env > 0 ? sx_env : F.ntx; }
+  F.dbg = nullptr;
+  sig_out.pa = pa; sig_out.pb = pb; sig_out.lz = F.lz; sig_out.nchunks = F.nchunks; sig_out.cstride = F.cstride; sig_out.step = steps;
+  HoGrid Hg;
+  Hg.fin = fin; Hg.fout = fout;
+  Hg.fplane = (long long)F.ncols * HoLayout<TY>::REC;
+  Hg.use_frames = (sig_in.step == steps - 1 && sig_in.same_geometry(sig_out)) ? 1 : 0;
+  dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
+  hipLaunchKernelGGL((k_fused_ho<TY>), grid, block, 0, stream, S, D, G, P, F, Hg);
+  return hipGetLastError() != hipSuccess;
+}
+
+#endif  // BFLBM_HANDOVER_H_

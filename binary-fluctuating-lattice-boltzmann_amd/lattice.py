@@ -79,6 +79,11 @@ class _DropletMixin:
         return tuple(p)
 
 
+# kernel schedules of include/bflbm.h (bflbm_set_schedule): "fused" = plane march with the ring densities pulled
+# (bit-exact), "handover" = plane march with the ring densities handed over from the previous step (tolerance)
+SCHEDULES = {"two_pass": 0, "fused": 1, "fused_exact": 1, "auto": 2, "handover": 3}
+
+
 class BinaryLBM(_DropletMixin):
     _droplet_fn = ("bflbm_droplet_moments", "bflbm_fit_droplet")
 
@@ -146,7 +151,7 @@ class BinaryLBM(_DropletMixin):
         check(self.lib.bflbm_set_params(self._h, ctypes.byref(self.params)))
 
     def set_schedule(self, schedule):
-        code = {"two_pass": 0, "fused": 1, "auto": 2}.get(schedule, schedule)
+        code = SCHEDULES.get(schedule, schedule)
         check(self.lib.bflbm_set_schedule(self._h, int(code)))
 
     # -- shapes ----------------------------------------------------------------------------
@@ -356,7 +361,7 @@ class RingLBM(_DropletMixin):
             z0, z1 = (self.n[2] * r) // nslabs, (self.n[2] * (r + 1)) // nslabs
             self.slabs.append(BinaryLBM._borrow(c, self.n, z0, z1, r, nslabs, self.params))
         if schedule is not None:
-            code = {"two_pass": 0, "fused": 1, "auto": 2}.get(schedule, schedule)
+            code = SCHEDULES.get(schedule, schedule)
             check(self.lib.bflbm_ring_set_schedule(self._h, int(code)))
 
     def close(self):
