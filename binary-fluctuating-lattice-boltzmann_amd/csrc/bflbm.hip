@@ -68,6 +68,8 @@ void derive(const bflbm_params& p, DevParams& d) {
     d.amp_f[a] = base * p.kBT / p.cs2 * kB[a];
     d.amp_g[a] = d.amp_f[a];
   }
+  const int rep[6] = {4, 5, 6, 7, 13, 16};       // one mode per distinct norm b[a]
+  for (int k = 0; k < 6; ++k) d.samp[k] = std::sqrt(d.amp_f[rep[k]]);
   d.seed_lo = (uint32_t)p.seed;
   d.seed_hi = (uint32_t)(p.seed >> 32);
   d.noise_on = (p.kBT != 0.) ? 1 : 0;
@@ -820,11 +822,10 @@ int bflbm_timer_stop(bflbm_ctx* c, float* ms) {
 
 int bflbm_rng_site_normals(uint64_t seed, uint64_t site, uint32_t noise_index, double* out36) {
   if (!out36) return fail("null argument");
-  for (uint32_t blk = 0; blk < 9; ++blk) {
-    float a, b, cc, d;
-    bflbm_rng_block((uint32_t)seed, (uint32_t)(seed >> 32), site, noise_index, blk, a, b, cc, d);
-    out36[4 * blk] = a; out36[4 * blk + 1] = b; out36[4 * blk + 2] = cc; out36[4 * blk + 3] = d;
-  }
+  static const float tab[BFLBM_NORMAL_TABLE_FLOATS] = BFLBM_NORMAL_TABLE_VALUES;
+  bflbm_rng_state st;
+  bflbm_rng_seed((uint32_t)seed, (uint32_t)(seed >> 32), site, noise_index, st);
+  for (int k = 0; k < 36; ++k) out36[k] = (k < 33) ? (double)bflbm_normal_from_bits(bflbm_rng_next(st), tab) : 0.;
   return 0;
 }
 

@@ -86,11 +86,9 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   static_assert((BFLBM_ABL & 1) || (NW % 2 == 0 && (2 * (TX + 2) + 2 * TY) <= 64 * (NW / 2)), "ring tasks of one fluid must fit one per lane of half the waves");
   __shared__ double rp[4][2][LSZ];               // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
   __shared__ double gl[Q][TX * TY];              // g populations of the previous plane
-#ifdef BFLBM_NOISE_EARLY
-  // MODE 1: the 18 normals of fluid f (stream blocks 0..4) of the plane collided next, drawn while the
-  // loads of the current plane are in flight (pure VALU work under memory latency); thread-private columns
-  __shared__ float nl[MODE == 1 ? 18 : 1][MODE == 1 ? TX * TY : 1];
-#endif
+  __shared__ float ntab[MODE == 1 ? BFLBM_NORMAL_TABLE_FLOATS : 4];
+  __shared__ double n3l[MODE == 1 ? 3 : 1][MODE == 1 ? TX * TY : 1];   // MODE 1: momentum-mode noise of the site being collided (thread-private column)
+  if (MODE == 1) d_load_normal_table(ntab, true);
 
   int col, chunk;
   if (!fused_map(F, (int)blockIdx.x, col, chunk)) return;   // whole workgroup leaves together
@@ -202,19 +200,6 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
       for (int i = 0; i < Q; ++i) hv[i] = 0.;
     }
     STAMP(0);                                   // loads issued
-#ifdef BFLBM_NOISE_EARLY
-    if (MODE == 1) {
-      if ((q - 1 >= qa) && (q - 1 < qb) && interior) {
-        const uint64_t site_prev = global_site(G, x, y, wrapp(q - 1));
-        float nr[20];
-#pragma unroll
-        for (uint32_t blk = 0; blk < 5; ++blk)
-          bflbm_rng_block(P.seed_lo, P.seed_hi, site_prev, noise_index, blk, nr[4*blk], nr[4*blk+1], nr[4*blk+2], nr[4*blk+3]);
-#pragma unroll
-        for (int k = 0; k < 18; ++k) nl[k][tid] = nr[k];
-      }
-    }
-#endif
     // 2. densities of plane q into the ring slot.  The sums start from an opaque zero defined HERE: with a
     // literal 0.0 the compiler sinks the first addition (0.0 + f_0) into the load blocks above and waits
     // for the first load before it issues the rest.
@@ -258,7 +243,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
       const int pc = wrapp(q - 1);
       // noise: momentum modes now (hydrovars needs them), the rest right before each relaxation
       double fn3[3] = {0., 0., 0.}, gn3[3] = {0., 0., 0.};
-      NoiseAmp NA; float n3 = 0.f; uint64_t site = 0;
+      NoiseAmp NA; bflbm_rng_state rst;
       const double* __restrict__ nb_f = nullptr; const double* __restrict__ nb_g = nullptr;
       long long nvol = 0; unsigned no = 0;
       if (MODE == 2) {
@@ -269,16 +254,10 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #pragma unroll
         for (int k = 0; k < 3; ++k) { fn3[k] = ld(nb_f + (1 + k) * nvol, no); gn3[k] = ld(nb_g + (1 + k) * nvol, no); }
       } else if (MODE == 1) {
-        site = global_site(G, x, y, pc);
         d_noise_amp(P, r, ph, r + ph, NA);
-#ifdef BFLBM_NOISE_EARLY
+        d_noise_head(P, NA, global_site(G, x, y, pc), noise_index, ntab, rst, fn3);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) fn3[k] = NA.sj * (double)nl[k][tid];
-#else
-        d_noise_head(P, NA, site, noise_index, fn3, n3);
-#endif
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gn3[k] = -fn3[k];
+        for (int k = 0; k < 3; ++k) { gn3[k] = -fn3[k]; n3l[k][tid] = fn3[k]; }
       }
       double* __restrict__ Dp = D + (long long)pc * G.plane;
       unsigned o = yo[1] + xo[1];
@@ -294,41 +273,36 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
         double v_b[3];
         d_barycentric(r, ph, Hy, v_b, R);
         {
-          double fn[Q];
           if (MODE == 2) {
+            double fn[Q];
 #pragma unroll
             for (int a = 0; a < Q; ++a) fn[a] = ld(nb_f + a * nvol, no);
+            d_relax<true>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn, R.cs4);
           } else if (MODE == 1) {
-#ifdef BFLBM_NOISE_EARLY
-            fn[0] = 0.; fn[1] = fn3[0]; fn[2] = fn3[1]; fn[3] = fn3[2];
-#pragma unroll
-            for (int a = 4; a < Q; ++a) fn[a] = NA.sf[d_noise_group(a)] * (double)nl[3 + (a - 4)][tid];
-            (void)n3;
-#else
-            d_noise_f(P, NA, site, noise_index, fn3, n3, fn);
-#endif
+            const double n3[3] = { n3l[0][tid], n3l[1][tid], n3l[2][tid] };     // reloaded: keeps the register budget
+            d_relax_generated(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, n3, sqrt(fabs(r)), ntab, rst, R.cs4);
           } else {
-#pragma unroll
-            for (int a = 0; a < Q; ++a) fn[a] = 0.;
+            const double zn[Q] = {0.};
+            d_relax<false>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, zn, R.cs4);
           }
-          d_relax<MODE != 0>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn, R.cs4);
           double out[Q];
           d_populations(mf, out);
 #pragma unroll
           for (int i = 0; i < Q; ++i) st(Dp + (long long)i * G.vol, o, out[i]);
         }
         {
-          double gn[Q];
           if (MODE == 2) {
+            double gn[Q];
 #pragma unroll
             for (int a = 0; a < Q; ++a) gn[a] = ld(nb_g + a * nvol, no);
+            d_relax<true>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn, R.cs4);
           } else if (MODE == 1) {
-            d_noise_g(P, NA, site, noise_index, fn3, gn);
+            const double n3[3] = { -n3l[0][tid], -n3l[1][tid], -n3l[2][tid] };
+            d_relax_generated(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, n3, sqrt(fabs(ph)), ntab, rst, R.cs4);
           } else {
-#pragma unroll
-            for (int a = 0; a < Q; ++a) gn[a] = 0.;
+            const double zn[Q] = {0.};
+            d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
           }
-          d_relax<MODE != 0>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn, R.cs4);
           double out[Q];
           d_populations(mg, out);
 #pragma unroll

@@ -151,6 +151,24 @@ __device__ __forceinline__ void gather_field(const double* __restrict__ fld, con
   for (int i = 0; i < Q; ++i) nb[i] = ld_sb(fld + I.pl[1 + Vel::cz[i]], I.o[1 + Vel::cy[i]][1 + Vel::cx[i]]);
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (workgroup b -> XCD b % 8), each with its own L2.  With
+// the identity mapping consecutive rows of a plane land on different XCDs and every XCD fetches the rho,phi
+// rows of its y-neighbours itself (measured: k_collide read 1.36x its algorithmic bytes).  This mapping gives
+// each XCD a contiguous band of rows of every plane (grid.x % 8 == 0; identity otherwise).
+#define BFLBM_SITE_FROM_BLOCK_XCD()                                     \
+  int bx_ = (int)blockIdx.x, by_ = (int)blockIdx.y;                     \
+  if ((gridDim.x & 7u) == 0u) {                                         \
+    const unsigned b_ = blockIdx.y*gridDim.x + blockIdx.x, band_ = gridDim.x >> 3;   \
+    const unsigned xcd_ = b_ & 7u, j_ = b_ >> 3;                        \
+    by_ = (int)(j_ / band_); bx_ = (int)(xcd_*band_ + j_ % band_);      \
+  }                                                                     \
+  const long long s_ = (long long)bx_*blockDim.x + threadIdx.x;         \
+  if (s_ >= G.plane) return;                                            \
+  const int p = p0 + by_;                                               \
+  const int y = (int)(s_ / G.pitch);                                    \
+  const int x = (int)(s_ - (long long)y*G.pitch);                       \
+  if (x >= G.nx) return;                                                /* row padding */
+
 #define BFLBM_SITE_FROM_BLOCK()                                         \
   const long long s_ = (long long)blockIdx.x*blockDim.x + threadIdx.x;  \
   if (s_ >= G.plane) return;                                            \
@@ -179,7 +197,9 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
                                                  const double* __restrict__ rho, const double* __restrict__ phi,
                                                  const double* __restrict__ injf, const double* __restrict__ injg,
                                                  Geo G, DevParams P, int p0, uint32_t noise_index, RefState Rf) {
-  BFLBM_SITE_FROM_BLOCK();
+  __shared__ float ntab[(NOISE && !INJECT) ? BFLBM_NORMAL_TABLE_FLOATS : 4];
+  if (NOISE && !INJECT) d_load_normal_table(ntab, true);
+  BFLBM_SITE_FROM_BLOCK_XCD();
   SiteOff I; site_offsets(G, x, y, p, I);
   double fs[Q], gs[Q];
   pull_site(S, G, I, fs, gs);
@@ -194,16 +214,15 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
   const long long nvol = (long long)(G.nzs - 2*G.H)*G.dplane;         // injected arrays, dense: [a][p-H][y][x]
   const long long no = (long long)(p - G.H)*G.dplane + (long long)y*G.nx + x;
   double fn3[3] = {0., 0., 0.}, gn3[3] = {0., 0., 0.};
-  NoiseAmp NA; float n3 = 0.f; uint64_t site = 0;
+  NoiseAmp NA; bflbm_rng_state rst;
   if (INJECT) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { fn3[k] = injf[(1 + k)*nvol + no]; gn3[k] = injg[(1 + k)*nvol + no]; }
   } else if (NOISE) {
     double ar, ap, at;
     noise_state(Rf, G, x, y, p, r, ph, ar, ap, at);
-    site = global_site(G, x, y, p);
     d_noise_amp(P, ar, ap, at, NA);
-    d_noise_head(P, NA, site, noise_index, fn3, n3);
+    d_noise_head(P, NA, global_site(G, x, y, p), noise_index, ntab, rst, fn3);
 #pragma unroll
     for (int k = 0; k < 3; ++k) gn3[k] = -fn3[k];
   }
@@ -219,37 +238,37 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
   double v_b[3];
   d_barycentric(r, ph, Hy, v_b, R);
   {
-    double fn[Q];
-    if (INJECT) {
-#pragma unroll
-      for (int a = 0; a < Q; ++a) fn[a] = injf[a*nvol + no];
-    } else if (NOISE) {
-      d_noise_f(P, NA, site, noise_index, fn3, n3, fn);
-    } else {
-#pragma unroll
-      for (int a = 0; a < Q; ++a) fn[a] = 0.;
-    }
     double m[Q];
     d_moments(fs, m);
-    d_relax<NOISE || INJECT>(P, m, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn, R.cs4);
+    if (INJECT) {
+      double fn[Q];
+#pragma unroll
+      for (int a = 0; a < Q; ++a) fn[a] = injf[a*nvol + no];
+      d_relax<true>(P, m, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn, R.cs4);
+    } else if (NOISE) {
+      d_relax_generated(P, m, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn3, NA.sr, ntab, rst, R.cs4);
+    } else {
+      const double zn[Q] = {0.};
+      d_relax<false>(P, m, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, zn, R.cs4);
+    }
     d_populations(m, fs);
 #pragma unroll
     for (int i = 0; i < Q; ++i) st_sb(Dp + (long long)i*G.vol, o, fs[i]);
   }
   {
-    double gn[Q];
-    if (INJECT) {
-#pragma unroll
-      for (int a = 0; a < Q; ++a) gn[a] = injg[a*nvol + no];
-    } else if (NOISE) {
-      d_noise_g(P, NA, site, noise_index, fn3, gn);
-    } else {
-#pragma unroll
-      for (int a = 0; a < Q; ++a) gn[a] = 0.;
-    }
     double m[Q];
     d_moments(gs, m);
-    d_relax<NOISE || INJECT>(P, m, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn, R.cs4);
+    if (INJECT) {
+      double gn[Q];
+#pragma unroll
+      for (int a = 0; a < Q; ++a) gn[a] = injg[a*nvol + no];
+      d_relax<true>(P, m, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn, R.cs4);
+    } else if (NOISE) {
+      d_relax_generated(P, m, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn3, NA.sp, ntab, rst, R.cs4);
+    } else {
+      const double zn[Q] = {0.};
+      d_relax<false>(P, m, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
+    }
     d_populations(m, gs);
 #pragma unroll
     for (int i = 0; i < Q; ++i) st_sb(Dp + (long long)(i+Q)*G.vol, o, gs[i]);
@@ -359,6 +378,8 @@ __global__ void __launch_bounds__(256) k_observe(const double* __restrict__ S, c
                                                  const double* __restrict__ injg, double* __restrict__ out,
                                                  Geo G, DevParams P, int p0, uint32_t noise_index, int ncomp, int inject,
                                                  RefState Rf) {
+  __shared__ float ntab[WHAT != 0 ? BFLBM_NORMAL_TABLE_FLOATS : 4];
+  if (WHAT != 0) d_load_normal_table(ntab, P.noise_on && !inject);
   BFLBM_SITE_FROM_BLOCK();
   SiteIdx I; site_index(G, x, y, p, I);
   double fs[Q], gs[Q];
@@ -387,7 +408,7 @@ __global__ void __launch_bounds__(256) k_observe(const double* __restrict__ S, c
   } else if (P.noise_on) {
     double ar, ap, at;
     noise_state(Rf, G, x, y, p, r, ph, ar, ap, at);
-    d_noise(P, ar, ap, at, global_site(G, x, y, p), noise_index, fn, gn);
+    d_noise(P, ar, ap, at, global_site(G, x, y, p), noise_index, ntab, fn, gn);
   } else {
 #pragma unroll
     for (int a = 0; a < Q; ++a) { fn[a] = 0.; gn[a] = 0.; }

@@ -3,12 +3,18 @@
 // The reference draws amrex::RandomNormal(0,1,engine) (LBM_binary.H:117,125,126),
 // an un-vendored generator whose stream depends on the box decomposition and
 // cannot be reproduced offline.  This project defines its own
-// stream instead: Philox4x32-10 keyed by `seed` with counter
-//   (site_lo, site_hi, noise_index, block)      block = 0..8, 4 normals each
-// where site = x + nx*(y + ny*z) is the GLOBAL lattice index, so the noise field is
-// independent of the slab decomposition and of the GPU count.  The Box-Muller
-// transform is written with binary32 + - * / sqrt only (no libm, no FMA) so the host
-// and the gfx950 kernels give identical bits.
+// stream instead (round 2: 2650 -> ~1100 VALU instructions per site):
+//   bits     one Philox4x32-10 block (KAT-checked) keyed by `seed` with counter
+//            (site_lo, site_hi, noise_index, 0) seeds xoshiro128++, which supplies the site's
+//            33 words (draw order: the 3 momentum modes, modes 4..18 of f, modes 4..18 of g);
+//            site = x + nx*(y + ny*z) is the GLOBAL lattice index, so the noise field is
+//            independent of the slab decomposition and of the GPU count;
+//   normals  table-driven inverse CDF: bit 31 is the sign, the other 31 bits are the tail
+//            probability t = P(|N| > x) as a binary fraction; its octave (leading zeros) and the
+//            next two bits select one of 128 cubics, the next 24 bits are the argument
+//            (tools/make_normal_table.py: max error 2.1e-6, variance 1 + 7e-8, <x^4> 3 - 1.3e-7;
+//            tails to 6.3 sigma).  Three binary32 FMAs -- exactly rounded on the host (fmaf) and on
+//            gfx950 (v_fma_f32) -- and integer operations only, so both give identical bits.
 #ifndef BFLBM_RNG_H_
 #define BFLBM_RNG_H_
 
@@ -59,83 +65,46 @@ BFLBM_HD uint32_t bflbm_f2u(float f) {
   union { uint32_t i; float f; } v; v.f = f; return v.i;
 #endif
 }
-
-BFLBM_HD float bflbm_sqrtf_rn(float x) {
+BFLBM_HD float bflbm_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }   // one rounding on both sides
+BFLBM_HD uint32_t bflbm_clz32(uint32_t v) {             // 32 for v == 0
 #if defined(__HIP_DEVICE_COMPILE__)
-  // __fsqrt_rn is not correctly rounded on gfx950 (measured: 15 % of inputs off by one ulp).
-  // sqrt in binary64 (correctly rounded on device, verified by tools/rng_probe.hip) then one
-  // rounding to binary32 is exact: 53 >= 2*24+2 bits rules out double rounding.
-  return (float)sqrt((double)x);
+  return (uint32_t)__clz((int)v);
 #else
-  return __builtin_sqrtf(x);
+  return v ? (uint32_t)__builtin_clz(v) : 32u;
 #endif
 }
-BFLBM_HD float bflbm_divf_rn(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __fdiv_rn(a, b);
-#else
-  return a / b;
-#endif
-}
+BFLBM_HD uint32_t bflbm_rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
 
-// ln(u), u in (0,1): exponent split + atanh series on [sqrt(1/2), sqrt(2)).
-BFLBM_HD float bflbm_logf(float u) {
-  uint32_t bits = bflbm_f2u(u);
-  int e = (int)(bits >> 23) - 127;
-  float m = bflbm_u2f((bits & 0x007FFFFFu) | 0x3F800000u);
-  if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
-  const float t = m - 1.0f;
-  const float s = bflbm_divf_rn(t, 2.0f + t);
-  const float z = s * s;
-  float p = 0.11111111f;
-  p = p * z + 0.14285714f;
-  p = p * z + 0.2f;
-  p = p * z + 0.33333333f;
-  p = p * z + 1.0f;
-  const float lnm = (2.0f * s) * p;
-  return (float)e * 0.69314718f + lnm;
+// xoshiro128++ (Blackman & Vigna): the site's word stream
+struct bflbm_rng_state { uint32_t s0, s1, s2, s3; };
+BFLBM_HD uint32_t bflbm_rng_next(bflbm_rng_state& s) {
+  const uint32_t result = bflbm_rotl32(s.s0 + s.s3, 7) + s.s0;
+  const uint32_t t = s.s1 << 9;
+  s.s2 ^= s.s0; s.s3 ^= s.s1; s.s1 ^= s.s2; s.s0 ^= s.s3;
+  s.s2 ^= t;
+  s.s3 = bflbm_rotl32(s.s3, 11);
+  return result;
 }
-
-// sin, cos of 2*pi*k/2^24
-BFLBM_HD void bflbm_sincos2pi(uint32_t k, float& sn, float& cs) {
-  const uint32_t q = k >> 22;
-  uint32_t r = k & 0x3FFFFFu;
-  const bool swap = r > 0x200000u;
-  if (swap) r = 0x400000u - r;
-  const float x = (float)r * 3.7450703e-07f;
-  const float x2 = x * x;
-  float ps = -1.9841270e-04f;
-  ps = ps * x2 + 8.3333333e-03f;
-  ps = ps * x2 - 1.6666667e-01f;
-  ps = ps * x2 + 1.0f;
-  float s = x * ps;
-  float pc = 2.4801587e-05f;
-  pc = pc * x2 - 1.3888889e-03f;
-  pc = pc * x2 + 4.1666667e-02f;
-  pc = pc * x2 - 0.5f;
-  pc = pc * x2 + 1.0f;
-  float c = pc;
-  if (swap) { const float t = s; s = c; c = t; }
-  sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
-  cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
-}
-
-BFLBM_HD void bflbm_box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-  const float u = ((float)(a >> 9) + 0.5f) * 1.1920929e-07f;
-  const float r = bflbm_sqrtf_rn(-2.0f * bflbm_logf(u));
-  float s, c;
-  bflbm_sincos2pi(b >> 8, s, c);
-  n0 = r * c;
-  n1 = r * s;
-}
-
-// Four standard normals of (site, noise_index, block).
-BFLBM_HD void bflbm_rng_block(uint32_t seed_lo, uint32_t seed_hi, uint64_t site, uint32_t noise_index,
-                              uint32_t blk, float& a, float& b, float& c, float& d) {
-  uint32_t c0 = (uint32_t)site, c1 = (uint32_t)(site >> 32), c2 = noise_index, c3 = blk;
+BFLBM_HD void bflbm_rng_seed(uint32_t seed_lo, uint32_t seed_hi, uint64_t site, uint32_t noise_index, bflbm_rng_state& s) {
+  uint32_t c0 = (uint32_t)site, c1 = (uint32_t)(site >> 32), c2 = noise_index, c3 = 0u;
   bflbm_philox4x32_10(c0, c1, c2, c3, seed_lo, seed_hi);
-  bflbm_box_muller(c0, c1, a, b);
-  bflbm_box_muller(c2, c3, c, d);
+  s.s0 = c0; s.s1 = c1; s.s2 = c2; s.s3 = c3 | 1u;     // never the all-zero state
+}
+
+#define BFLBM_NORMAL_TABLE_FLOATS 512
+// standard normal from one 32-bit word; tab = the 128 cubics of bflbm_normal_table.h (LDS on the device)
+template <typename TabPtr>
+BFLBM_HD float bflbm_normal_from_bits(uint32_t u, TabPtr tab) {
+  const uint32_t sign = u & 0x80000000u, v = u & 0x7FFFFFFFu;
+  const uint32_t lz = bflbm_clz32(v);                   // 1..32: octave + 1
+  const uint32_t top = (lz >= 32u) ? 0u : (v << lz);    // leading one at bit 31
+  const uint32_t r = top << 1;                          // the bits after it, left-aligned
+  const uint32_t oct = (lz >= 32u) ? 31u : lz - 1u;
+  const uint32_t cell = oct * 4u + (r >> 30);
+  const float W = (float)((r >> 6) & 0xFFFFFFu);        // 24 bits: exact
+  const float c0 = tab[cell * 4u + 0u], c1 = tab[cell * 4u + 1u], c2 = tab[cell * 4u + 2u], c3 = tab[cell * 4u + 3u];
+  const float x = bflbm_fmaf(bflbm_fmaf(bflbm_fmaf(c3, W, c2), W, c1), W, c0);
+  return bflbm_u2f(bflbm_f2u(x) ^ sign);
 }
 
 #endif  // BFLBM_RNG_H_

@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <float.h>
 #include "bflbm_rng.h"
+#include "bflbm_normal_table.h"
 
 #define Q 19
 
@@ -35,6 +36,7 @@ struct DevParams {
   double mod2;                  // modifactor*2.                     (:431, :433)
   double amp_j;                 // 2.*(tfb-0.5*tfb2)*kBT             (:117)
   double amp_f[Q], amp_g[Q];    // 2.*(tfb-0.5*tfb2)*kBT/cs2*b[a]    (:125-126)
+  double samp[6];               // sqrt(amp_f[a]) for the six distinct mode norms (a = 4, 5, 6, 7, 13, 16)
   uint32_t seed_lo, seed_hi;
   int noise_on;                 // kBT != 0
 };
@@ -261,12 +263,13 @@ __device__ __forceinline__ void d_gradient(const DevParams& P, const double (&nb
 }
 
 // thermal_noise (LBM_binary.H:73-132) for one site.  The amplitude of mode a >= 4 is
-// sqrt(amp[a]*|rho|) with amp[a] proportional to the mode norm b[a]; b takes only six distinct
-// values (2/3, 4/3, 4/9, 1/9, 2/9, 2; LBM_d3q19.H:56-76), so 6 square roots per fluid give the
-// same doubles as the reference's 15.  Normals: blocks 0..4 of the site's stream feed fluid f
-// (and the shared momentum modes), blocks 5..8 fluid g, so each fluid's noise can be generated
-// right before its relaxation.
-struct NoiseAmp { double sj, sf[6], sg[6]; };
+// sqrt(c*b[a]*|rho|), c = 2(tb - tb^2/2) kBT/cs2, with the mode norm b[a] taking only six distinct values
+// (2/3, 4/3, 4/9, 1/9, 2/9, 2; LBM_d3q19.H:56-76): sqrt(c*b) is uniform (host, DevParams.samp) and the site
+// contributes sqrt|rho|, sqrt|phi| -- 3 square roots per site instead of the 31 of the reference's loop.  (The
+// generated noise is pinned statistically only; the oracle restates the same factorisation, so GPU and
+// oracle agree bit for bit.)  Normals: the site's word stream, bflbm_rng.h; words 0..2 the momentum modes shared
+// by both fluids, 3..17 fluid f, 18..32 fluid g, so each fluid's noise is generated right before its relaxation.
+struct NoiseAmp { double sj, sr, sp; };          // sqrt(amp_j |rho phi/rhot|), sqrt|rho|, sqrt|phi|
 __device__ __forceinline__ int d_noise_group(int a) {   // modes 4..18 -> index of b[a] among the six values
   return (a == 4 || (a >= 10 && a <= 12)) ? 0 : (a == 5 || a == 17) ? 1 : (a == 6 || a == 18) ? 2
        : (a >= 7 && a <= 9) ? 3 : (a >= 13 && a <= 15) ? 4 : 5;
@@ -275,47 +278,49 @@ __device__ __forceinline__ int d_noise_group(int a) {   // modes 4..18 -> index 
 // rhot = rho + phi (LBM_binary.H:109-111) or the reference state under USE_REF_STATE (:92-107).
 __device__ __forceinline__ void d_noise_amp(const DevParams& P, double rho, double phi, double rhot, NoiseAmp& A) {
   A.sj = sqrt(P.amp_j * fabs(rho*phi/rhot));
-  const double arho = fabs(rho), aphi = fabs(phi);
-  const int rep[6] = {4, 5, 6, 7, 13, 16};
-#pragma unroll
-  for (int k = 0; k < 6; ++k) { A.sf[k] = sqrt(P.amp_f[rep[k]] * arho); A.sg[k] = sqrt(P.amp_g[rep[k]] * aphi); }
+  A.sr = sqrt(fabs(rho)); A.sp = sqrt(fabs(phi));
 }
-// momentum-mode noise (modes 1..3 of f; g gets the negative) and the normal of f mode 4
-__device__ __forceinline__ void d_noise_head(const DevParams& P, const NoiseAmp& A, uint64_t site, uint32_t idx,
-                                             double (&fn3)[3], float& n3) {
-  float n0, n1, n2;
-  bflbm_rng_block(P.seed_lo, P.seed_hi, site, idx, 0u, n0, n1, n2, n3);
-  fn3[0] = A.sj * (double)n0; fn3[1] = A.sj * (double)n1; fn3[2] = A.sj * (double)n2;
+// noise of mode a >= 4 of one fluid (s = A.sr or A.sp), drawing the next word of the site's stream
+template <typename Tab>
+__device__ __forceinline__ double d_noise_mode(const DevParams& P, double s, int a, Tab tab, bflbm_rng_state& st) {
+  return (P.samp[d_noise_group(a)] * s) * (double)bflbm_normal_from_bits(bflbm_rng_next(st), tab);
 }
-__device__ __forceinline__ void d_noise_f(const DevParams& P, const NoiseAmp& A, uint64_t site, uint32_t idx,
-                                          const double (&fn3)[3], float n3, double (&fn)[Q]) {
-  float nrm[20];
-  nrm[3] = n3;
+// seeds the site's stream and draws the momentum-mode noise (modes 1..3 of f; g gets the negative)
+template <typename Tab>
+__device__ __forceinline__ void d_noise_head(const DevParams& P, const NoiseAmp& A, uint64_t site, uint32_t idx, Tab tab,
+                                             bflbm_rng_state& st, double (&fn3)[3]) {
+  bflbm_rng_seed(P.seed_lo, P.seed_hi, site, idx, st);
 #pragma unroll
-  for (uint32_t blk = 1; blk < 5; ++blk)
-    bflbm_rng_block(P.seed_lo, P.seed_hi, site, idx, blk, nrm[4*blk], nrm[4*blk+1], nrm[4*blk+2], nrm[4*blk+3]);
+  for (int k = 0; k < 3; ++k) fn3[k] = A.sj * (double)bflbm_normal_from_bits(bflbm_rng_next(st), tab);
+}
+template <typename Tab>
+__device__ __forceinline__ void d_noise_f(const DevParams& P, const NoiseAmp& A, Tab tab, bflbm_rng_state& st, const double (&fn3)[3], double (&fn)[Q]) {
   fn[0] = 0.; fn[1] = fn3[0]; fn[2] = fn3[1]; fn[3] = fn3[2];
 #pragma unroll
-  for (int a = 4; a < Q; ++a) fn[a] = A.sf[d_noise_group(a)] * (double)nrm[3 + (a-4)];
+  for (int a = 4; a < Q; ++a) fn[a] = d_noise_mode(P, A.sr, a, tab, st);
 }
-__device__ __forceinline__ void d_noise_g(const DevParams& P, const NoiseAmp& A, uint64_t site, uint32_t idx,
-                                          const double (&fn3)[3], double (&gn)[Q]) {
-  float nrm[16];
-#pragma unroll
-  for (uint32_t blk = 5; blk < 9; ++blk)
-    bflbm_rng_block(P.seed_lo, P.seed_hi, site, idx, blk, nrm[4*(blk-5)], nrm[4*(blk-5)+1], nrm[4*(blk-5)+2], nrm[4*(blk-5)+3]);
+template <typename Tab>
+__device__ __forceinline__ void d_noise_g(const DevParams& P, const NoiseAmp& A, Tab tab, bflbm_rng_state& st, const double (&fn3)[3], double (&gn)[Q]) {
   gn[0] = 0.; gn[1] = -fn3[0]; gn[2] = -fn3[1]; gn[3] = -fn3[2];
 #pragma unroll
-  for (int a = 4; a < Q; ++a) gn[a] = A.sg[d_noise_group(a)] * (double)nrm[a-4];
+  for (int a = 4; a < Q; ++a) gn[a] = d_noise_mode(P, A.sp, a, tab, st);
 }
-// all 38 noise moments (two-pass schedule, observables)
+// all 38 noise moments (observables)
+template <typename Tab>
 __device__ __forceinline__ void d_noise(const DevParams& P, double rho, double phi, double rhot, uint64_t site,
-                                        uint32_t noise_index, double (&fn)[Q], double (&gn)[Q]) {
+                                        uint32_t noise_index, Tab tab, double (&fn)[Q], double (&gn)[Q]) {
   NoiseAmp A; d_noise_amp(P, rho, phi, rhot, A);
-  double fn3[3]; float n3;
-  d_noise_head(P, A, site, noise_index, fn3, n3);
-  d_noise_f(P, A, site, noise_index, fn3, n3, fn);
-  d_noise_g(P, A, site, noise_index, fn3, gn);
+  double fn3[3]; bflbm_rng_state st;
+  d_noise_head(P, A, site, noise_index, tab, st, fn3);
+  d_noise_f(P, A, tab, st, fn3, fn);
+  d_noise_g(P, A, tab, st, fn3, gn);
+}
+
+// the normal table in LDS: every thread of the workgroup calls this before any early exit
+__constant__ float bflbm_normal_table_dev[BFLBM_NORMAL_TABLE_FLOATS] = BFLBM_NORMAL_TABLE_VALUES;
+__device__ __forceinline__ void d_load_normal_table(float* lds, bool wanted) {
+  if (wanted) for (int i = threadIdx.x; i < BFLBM_NORMAL_TABLE_FLOATS; i += blockDim.x) lds[i] = bflbm_normal_table_dev[i];
+  __syncthreads();
 }
 
 // The quantities hydrovars() derives per site (LBM_binary.H:196-295) that collide() consumes.
@@ -405,25 +410,46 @@ __device__ __forceinline__ void d_force_moments(const DevParams& P, double rho, 
 // The relaxation loop of collide (LBM_binary.H:504-511) for one fluid, in moment space:
 // m += (mEq - m)/tau_bar + mPhi + noise, with the fluid's density rho_k, the barycentric
 // velocity v_b (equilibrium), its own real velocity u and acceleration a (force moments).
-template <bool NOISE>
-__device__ __forceinline__ void d_relax(const DevParams& P, double (&m)[Q], double rho_k, const double (&v_b)[3],
-                                        const double (&u)[3], const double (&a)[3], double inv_tau_bar,
-                                        const double (&noise)[Q], double ycs4) {
+// The noise of mode k is asked from `noise(k)` in mode order right where it is added (a generated stream never
+// exists as an array of 19 doubles); NOISE=false drops the terms (they are exactly +-0 when kBT == 0).
+template <bool NOISE, typename NoiseFn>
+__device__ __forceinline__ void d_relax_with(const DevParams& P, double (&m)[Q], double rho_k, const double (&v_b)[3],
+                                             const double (&u)[3], const double (&a)[3], double inv_tau_bar,
+                                             NoiseFn noise, double ycs4) {
   double mEq[10], mPhi[10];
   d_equilibrium(P, rho_k, v_b, mEq, ycs4);
   d_force_moments(P, rho_k, u, a, mPhi, ycs4);
 #pragma unroll
   for (int k = 0; k < 10; ++k) {
     double R = inv_tau_bar*(mEq[k] - m[k]) + mPhi[k];
-    if (NOISE) R = R + noise[k];
+    if (NOISE) R = R + noise(k);
     m[k] = m[k] + R;
   }
 #pragma unroll
   for (int k = 10; k < Q; ++k) {
     double R = inv_tau_bar*(0. - m[k]) + 0.;
-    if (NOISE) R = R + noise[k];
+    if (NOISE) R = R + noise(k);
     m[k] = m[k] + R;
   }
+}
+template <bool NOISE>
+__device__ __forceinline__ void d_relax(const DevParams& P, double (&m)[Q], double rho_k, const double (&v_b)[3],
+                                        const double (&u)[3], const double (&a)[3], double inv_tau_bar,
+                                        const double (&noise)[Q], double ycs4) {
+  d_relax_with<NOISE>(P, m, rho_k, v_b, u, a, inv_tau_bar, [&](int k) { return noise[k]; }, ycs4);
+}
+// relaxation of one fluid with the generated stream: n3 = its momentum-mode noise (fn3 or -fn3), s = A.sr / A.sp.
+// The fluid's 15 normals are drawn first as binary32 (their 15 table look-ups are in flight together), the
+// doubles are formed where they are added.
+template <typename Tab>
+__device__ __forceinline__ void d_relax_generated(const DevParams& P, double (&m)[Q], double rho_k, const double (&v_b)[3],
+                                                  const double (&u)[3], const double (&a)[3], double inv_tau_bar,
+                                                  const double (&n3)[3], double s, Tab tab, bflbm_rng_state& st, double ycs4) {
+  float nrm[Q - 4];
+#pragma unroll
+  for (int k = 4; k < Q; ++k) nrm[k - 4] = bflbm_normal_from_bits(bflbm_rng_next(st), tab);
+  d_relax_with<true>(P, m, rho_k, v_b, u, a, inv_tau_bar,
+                     [&](int k) { return k == 0 ? 0. : (k < 4 ? n3[k - 1] : (P.samp[d_noise_group(k)] * s) * (double)nrm[k - 4]); }, ycs4);
 }
 
 __device__ __forceinline__ void d_barycentric(double rho, double phi, const SiteHydro& H, double (&v_b)[3], const SiteRecip& R) {

@@ -465,7 +465,7 @@ class RingLBM(_DropletMixin):
 
 
 def rng_site_normals(seed, site, noise_index):
-    """Host evaluation of the project's Gaussian stream (36 values per site and index)."""
+    """Host evaluation of the project's Gaussian stream: the 33 normals of one site and noise index."""
     out = (ctypes.c_double * 36)()
     check(_lib.load().bflbm_rng_site_normals(int(seed), int(site), int(noise_index), out))
-    return np.array(list(out))
+    return np.array(list(out))[:33]

@@ -253,7 +253,8 @@ int bflbm_timer_start(bflbm_ctx* c);
 int bflbm_timer_stop(bflbm_ctx* c, float* ms);
 
 /* Host-side evaluation of the project's counter-based Gaussian stream (the HIP
- * kernels use the same code); 36 values, 33 consumed per site and noise index. */
+ * kernels use the same code): out36[0..32] = the 33 normals of the site and noise index (3 momentum
+ * modes, 15 modes of f, 15 modes of g), out36[33..35] = 0. */
 int bflbm_rng_site_normals(uint64_t seed, uint64_t site, uint32_t noise_index, double* out36);
 
 /* Diagnostics: time `reps` launches of a streaming kernel over the slab (hipEvents), for

@@ -224,13 +224,19 @@ void orc_populations(const double* mom, double* f) {
 }
 
 /* ------------------------------------------------------------------ */
-/* Project RNG: Philox4x32-10 (Salmon et al., SC'11) keyed by the seed,
- * counter = (global site id lo/hi, noise index, draw block), followed by a
- * Box-Muller transform in binary32 built from + - * and correctly rounded
- * sqrt/divide only (no libm), so that the HIP kernels reproduce it bit for
- * bit.  It replaces amrex::RandomNormal (LBM_binary.H:117,125,126), whose
- * stream is not available offline.  The product-side definition lives in
- * csrc/bflbm_rng.h; tests/test_rng.py checks the two agree. */
+/* Project RNG (replaces amrex::RandomNormal, LBM_binary.H:117,125,126, whose stream is not available
+ * offline -- parity unpinned at that boundary).  Per (site, noise index): one Philox4x32-10
+ * block (Salmon et al., SC'11) keyed by the seed with counter (site lo, site hi, noise index, 0) seeds
+ * xoshiro128++ (Blackman & Vigna), whose first 33 words become the site's 33 normals through a
+ * table-driven inverse CDF: bit 31 = sign, the other 31 bits = tail probability P(|N| > x) as a binary
+ * fraction; octave (leading zeros) and the next two bits pick one of 128 cubics (normal_table.h, generated
+ * by tools/make_normal_table.py), the next 24 bits are its argument; three binary32 FMAs (fmaf: one
+ * rounding each), integer operations otherwise, so the HIP kernels reproduce it bit for bit.  The
+ * product-side definition lives in csrc/bflbm_rng.h; tests/test_oracle_pins.py and tests/test_gpu_noise.py
+ * check that the two agree. */
+#include "normal_table.h"
+static const float NORMAL_TABLE[512] = ORC_NORMAL_TABLE_VALUES;
+
 static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                  uint32_t k0, uint32_t k1, uint32_t out[4]) {
   for (int r = 0; r < 10; ++r) {
@@ -246,76 +252,39 @@ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* ln(u) for u in (0,1), binary32 arithmetic, fixed operation order. */
-static inline float rng_logf(float u) {
-  union { float f; uint32_t i; } v; v.f = u;
-  int e = (int)(v.i >> 23) - 127;
-  v.i = (v.i & 0x007FFFFFu) | 0x3F800000u;      /* mantissa in [1,2) */
-  float m = v.f;
-  if (m > 1.41421356f) { m = m * 0.5f; e += 1; } /* [sqrt(1/2), sqrt(2)) */
-  float t = m - 1.0f;
-  float s = t / (2.0f + t);                      /* atanh argument, |s| < 0.1716 */
-  float z = s * s;
-  /* ln(m) = 2 s (1 + z/3 + z^2/5 + z^3/7 + z^4/9) */
-  float p = 0.11111111f;
-  p = p * z + 0.14285714f;
-  p = p * z + 0.2f;
-  p = p * z + 0.33333333f;
-  p = p * z + 1.0f;
-  float lnm = (2.0f * s) * p;
-  return (float)e * 0.69314718f + lnm;
+static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+static inline uint32_t xoshiro128pp(uint32_t s[4]) {
+  const uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
+  const uint32_t t = s[1] << 9;
+  s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+  s[2] ^= t;
+  s[3] = rotl32(s[3], 11);
+  return result;
 }
 
-/* sin and cos of 2*pi*k/2^24 for a 24-bit integer k, binary32 arithmetic. */
-static inline void rng_sincos2pi(uint32_t k, float* sn, float* cs) {
-  uint32_t q = k >> 22;             /* quadrant */
-  uint32_t r = k & 0x3FFFFFu;       /* position inside the quadrant, 22 bits */
-  int swap = r > 0x200000u;         /* fold to [0, pi/4] */
-  if (swap) r = 0x400000u - r;
-  float x = (float)r * 3.7450703e-07f; /* (pi/2) / 2^22 */
-  float x2 = x * x;
-  float ps = -1.9841270e-04f;
-  ps = ps * x2 + 8.3333333e-03f;
-  ps = ps * x2 - 1.6666667e-01f;
-  ps = ps * x2 + 1.0f;
-  float s = x * ps;
-  float pc = 2.4801587e-05f;
-  pc = pc * x2 - 1.3888889e-03f;
-  pc = pc * x2 + 4.1666667e-02f;
-  pc = pc * x2 - 0.5f;
-  pc = pc * x2 + 1.0f;
-  float c = pc;
-  if (swap) { float t = s; s = c; c = t; }
-  switch (q) {
-    case 0: *sn = s;  *cs = c;  break;
-    case 1: *sn = c;  *cs = -s; break;
-    case 2: *sn = -s; *cs = -c; break;
-    default:*sn = -c; *cs = s;  break;
+/* one standard normal from one 32-bit word */
+static inline float normal_from_bits(uint32_t u) {
+  const uint32_t sign = u & 0x80000000u, v = u & 0x7FFFFFFFu;
+  uint32_t oct, r;
+  if (v == 0u) { oct = 31u; r = 0u; }
+  else {
+    const uint32_t lz = (uint32_t)__builtin_clz(v);   /* >= 1: bit 31 is clear */
+    oct = lz - 1u;                                     /* t in [2^-(oct+1), 2^-oct) */
+    r = (v << lz) << 1;                                /* the bits after the leading one, left-aligned */
   }
+  const float* c = NORMAL_TABLE + 4u*(oct*4u + (r >> 30));
+  const float W = (float)((r >> 6) & 0xFFFFFFu);
+  const float x = fmaf(fmaf(fmaf(c[3], W, c[2]), W, c[1]), W, c[0]);
+  union { float f; uint32_t i; } o; o.f = x; o.i ^= sign;
+  return o.f;
 }
 
-/* two standard normals from two 32-bit words */
-static inline void rng_box_muller(uint32_t a, uint32_t b, float* n0, float* n1) {
-  float u = ((float)(a >> 9) + 0.5f) * 1.1920929e-07f;   /* (k+1/2)/2^23 in (0,1) */
-  float r = sqrtf(-2.0f * rng_logf(u));
-  float s, c;
-  rng_sincos2pi(b >> 8, &s, &c);
-  *n0 = r * c;
-  *n1 = r * s;
-}
-
-/* The 36 normals of one site for one noise index (33 are consumed). */
+/* The 33 normals of one site for one noise index (out36[33..35] = 0; the array length is the C-ABI's). */
 void orc_site_normals(uint64_t seed, uint64_t site, uint32_t noise_index, double* out36) {
-  for (uint32_t blk = 0; blk < 9; ++blk) {
-    uint32_t w[4];
-    philox4x32_10((uint32_t)site, (uint32_t)(site >> 32), noise_index, blk,
-                  (uint32_t)seed, (uint32_t)(seed >> 32), w);
-    float a, b, c, d;
-    rng_box_muller(w[0], w[1], &a, &b);
-    rng_box_muller(w[2], w[3], &c, &d);
-    out36[4*blk+0] = (double)a; out36[4*blk+1] = (double)b;
-    out36[4*blk+2] = (double)c; out36[4*blk+3] = (double)d;
-  }
+  uint32_t s[4];
+  philox4x32_10((uint32_t)site, (uint32_t)(site >> 32), noise_index, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), s);
+  s[3] |= 1u;                                          /* never the all-zero state */
+  for (int k = 0; k < 36; ++k) out36[k] = (k < 33) ? (double)normal_from_bits(xoshiro128pp(s)) : 0.;
 }
 
 void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
@@ -366,9 +335,11 @@ static void thermal_noise_impl(const orc_params* p, int nx, int ny, int nz, int 
     uint64_t site = (uint64_t)x + (uint64_t)nx*((uint64_t)y + (uint64_t)ny*(uint64_t)gz);
     orc_site_normals(p->seed, site, noise_index, nrm);
     /* Assignment of the site's normals to modes (project-defined, like the stream itself):
-     * nrm[0..2] -> momentum modes 1..3 (gn = -fn), nrm[3 + (a-4)] -> f mode a (blocks 0..4),
-     * nrm[20 + (a-4)] -> g mode a (blocks 5..8); a = 4..18.  The reference interleaves f,g draws
-     * (:124-127), which is immaterial for an i.i.d. stream. */
+     * nrm[0..2] -> momentum modes 1..3 (gn = -fn), nrm[3 + (a-4)] -> f mode a, nrm[18 + (a-4)] -> g mode a;
+     * a = 4..18.  The reference interleaves f,g draws (:124-127), which is immaterial for an i.i.d. stream.
+     * Amplitudes (:117, :125-126): sqrt(c kBT |rho phi/rhot|) and sqrt(c kBT/cs2 b[a] |rho|), the latter
+     * evaluated as sqrt(c kBT/cs2 b[a]) * sqrt(|rho|) -- the same number to an ulp with 3 instead of 31 square
+     * roots per site; project-defined like the stream (the generated noise is pinned statistically only). */
     fn[IDX(nx,ny,nz,0,x,y,z)] = 0.;
     gn[IDX(nx,ny,nz,0,x,y,z)] = 0.;
     for (int a = 1; a <= 3; a++) {
@@ -376,9 +347,10 @@ static void thermal_noise_impl(const orc_params* p, int nx, int ny, int nz, int 
       fn[IDX(nx,ny,nz,a,x,y,z)] = v;
       gn[IDX(nx,ny,nz,a,x,y,z)] = -v;
     }
+    const double sr = sqrt(fabs(rho)), sp = sqrt(fabs(phi));
     for (int a = 4; a < Q; a++) {
-      fn[IDX(nx,ny,nz,a,x,y,z)] = sqrt(2.*(tau_f_bar - 0.5*tau_f_bar2)*kBT/cs2*B[a]*fabs(rho))*nrm[3 + (a-4)];
-      gn[IDX(nx,ny,nz,a,x,y,z)] = sqrt(2.*(tau_g_bar - 0.5*tau_g_bar2)*kBT/cs2*B[a]*fabs(phi))*nrm[20 + (a-4)];
+      fn[IDX(nx,ny,nz,a,x,y,z)] = sqrt(2.*(tau_f_bar - 0.5*tau_f_bar2)*kBT/cs2*B[a])*sr*nrm[3 + (a-4)];
+      gn[IDX(nx,ny,nz,a,x,y,z)] = sqrt(2.*(tau_g_bar - 0.5*tau_g_bar2)*kBT/cs2*B[a])*sp*nrm[18 + (a-4)];
     }
   }
 }

@@ -71,7 +71,7 @@ def lattice_tables():
 def site_normals(seed, site, noise_index):
     out = np.empty(36)
     lib().orc_site_normals(ctypes.c_uint64(seed), ctypes.c_uint64(site), ctypes.c_uint32(noise_index), _p(out))
-    return out
+    return out[:33].copy()
 
 
 class OracleLattice:

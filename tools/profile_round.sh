@@ -3,7 +3,7 @@
 # usage: tools/profile_round.sh <tag> [bench args]
 set -e
 tag=$1; shift
-out=gpurun_out/$tag; mkdir -p $out
+out=gpurun_out/$tag; rm -rf $out; mkdir -p $out     # one session per tag: the summary must describe this run only
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline "$@" > $out/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $out/fetch.log 2>&1
