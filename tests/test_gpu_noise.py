@@ -10,8 +10,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_noise_mode_variances_256(pkg, ob):
-    """NoiseCovariance.ipynb cell 3: per-mode variance / theory -> mean 1.00041 (16^3 x 200 frames).
+def test_noise_mode_variances_128(pkg, ob):
+    """NoiseCovariance.ipynb cell 3: per-mode variance / theory -> mean 1.00041 (16^3 x 200 frames).  (The real
+    256^3 of configs[2] is tests/test_gpu_configs.py::test_config2_noise_mode_variances_at_256_cubed.)
     One 128^3 frame has 2.1e6 samples per mode: standard error of a variance ratio = sqrt(2/N) = 1e-3;
     assert |ratio-1| < 0.5 % (5 sigma) per mode and < 0.15 % for the mean over modes."""
     n = 128
