@@ -2,6 +2,7 @@
 // Host side: context, HBM layout, launches, FAB <-> slab copies.  No torch, no oracle.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -872,21 +873,29 @@ int bflbm_device_bytes(const bflbm_ctx* c, size_t* bytes) {
 struct bflbm_ring {
   std::vector<bflbm_ctx*> ctx;
   std::vector<hipStream_t> comm;        // per slab: copies + unpack, concurrent with the interior kernel
-  std::vector<hipEvent_t> packed;       // per slab: both faces packed (recorded on the slab's main stream)
+  std::vector<hipEvent_t> packed;       // per slab: the planes its neighbours copy are final (recorded on the slab's main stream)
   std::vector<hipEvent_t> unpacked;     // per slab: both halo faces stored (recorded on the comm stream)
-  std::vector<double*> send[2], recv[2];
+  std::vector<std::array<bool, 2>> peer_ok;   // per slab: kernels on its device may read the lower / upper neighbour's memory
   size_t bytes = 0;
 };
 
-static int ring_exchange(bflbm_ring* r, int kind) {
+// Halo exchange of the ring without staging: every (component, plane) entry of the halo table is one
+// contiguous plane (pitch*ny doubles) in the source slab and in the destination slab, so each face is moved by
+// 38 direct copies  neighbour's state -> my halo planes  on my comm stream (SDMA / xGMI between GPUs, a device
+// copy on one GPU): 2 x plane bytes of traffic per entry instead of the 6 x of pack -> copy -> unpack.
+static int ring_mark(bflbm_ring* r) {
   const int n = (int)r->ctx.size();
   if (n == 1) return 0;
   for (int k = 0; k < n; ++k) {
     bflbm_ctx* c = r->ctx[k];
-    if (bflbm_halo_pack(c, kind, 0, r->send[0][k])) return 1;
-    if (bflbm_halo_pack(c, kind, 1, r->send[1][k])) return 1;
-    HIP_TRY(hipEventRecord(r->packed[k], c->stream));
+    HIP_TRY(hipSetDevice(c->dom.device));
+    HIP_TRY(hipEventRecord(r->packed[k], c->stream));            // my face planes are final from here on
   }
+  return 0;
+}
+static int ring_copy(bflbm_ring* r, int kind) {
+  const int n = (int)r->ctx.size();
+  if (n == 1) return 0;
   for (int k = 0; k < n; ++k) {
     bflbm_ctx* c = r->ctx[k];
     const int lower = (k + n - 1) % n, upper = (k + 1) % n;
@@ -894,20 +903,36 @@ static int ring_exchange(bflbm_ring* r, int kind) {
     HIP_TRY(hipStreamWaitEvent(r->comm[k], r->packed[lower], 0));
     HIP_TRY(hipStreamWaitEvent(r->comm[k], r->packed[upper], 0));
     HIP_TRY(hipStreamWaitEvent(r->comm[k], r->packed[k], 0));     // my own halo planes must not be overwritten earlier
-    // my low halo <- lower neighbour's high face; my high halo <- upper neighbour's low face
-    HIP_TRY(hipMemcpyPeerAsync(r->recv[0][k], c->dom.device, r->send[1][lower], r->ctx[lower]->dom.device, r->bytes, r->comm[k]));
-    HIP_TRY(hipMemcpyPeerAsync(r->recv[1][k], c->dom.device, r->send[0][upper], r->ctx[upper]->dom.device, r->bytes, r->comm[k]));
+    const size_t pbytes = (size_t)c->G.plane * sizeof(double);
     for (int side = 0; side < 2; ++side) {
-      HaloTable T; halo_table(c, kind, side, false, T);
-      hipLaunchKernelGGL(k_halo_unpack, plane_grid(c, 2 * Q), dim3(256), 0, r->comm[k], halo_buffer(c, kind),
-                         (const double*)r->recv[side][k], c->G, T);
+      // my low halo (side 0) <- lower neighbour's high face (its pack side 1); my high halo <- upper neighbour's low face
+      bflbm_ctx* src = r->ctx[side == 0 ? lower : upper];
+      HaloTable Tu, Tp;
+      halo_table(c, kind, side, false, Tu);
+      halo_table(src, kind, 1 - side, true, Tp);
+      double* dst_base = halo_buffer(c, kind);
+      const double* src_base = halo_buffer(src, kind);
+      for (int e = 0; e < 2 * Q; ++e) if (Tu.comp[e] != Tp.comp[e]) return fail("halo tables of neighbouring slabs disagree");
+      const bool reachable = (src->dom.device == c->dom.device) || r->peer_ok[k][side];
+      if (reachable && (c->G.plane % 2 == 0) && (c->G.vol % 2 == 0) && (src->G.vol % 2 == 0)) {
+        // one gather kernel per face reads the neighbour's planes in place (peer memory over xGMI between GPUs)
+        dim3 g((unsigned)((c->G.plane / 2 + 255) / 256), (unsigned)(2 * Q));
+        hipLaunchKernelGGL(k_halo_pull, g, dim3(256), 0, r->comm[k], dst_base, src_base, c->G.plane, c->G.vol, src->G.vol, Tu, Tp);
+        HIP_TRY(hipGetLastError());
+      } else {
+        for (int e = 0; e < 2 * Q; ++e) {
+          double* d = dst_base + (size_t)Tu.comp[e] * c->G.vol + (size_t)Tu.plane[e] * c->G.plane;
+          const double* sp = src_base + (size_t)Tp.comp[e] * src->G.vol + (size_t)Tp.plane[e] * src->G.plane;
+          HIP_TRY(hipMemcpyPeerAsync(d, c->dom.device, sp, src->dom.device, pbytes, r->comm[k]));
+        }
+      }
     }
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(r->unpacked[k], r->comm[k]));
     if (kind == BFLBM_HALO_STATE) c->density_valid = false;
   }
   return 0;
 }
+static int ring_exchange(bflbm_ring* r, int kind) { return ring_mark(r) || ring_copy(r, kind); }
 
 // everything later on a slab's main stream sees the stored halos
 static int ring_join(bflbm_ring* r) {
@@ -916,7 +941,7 @@ static int ring_join(bflbm_ring* r) {
   for (int k = 0; k < n; ++k) {
     HIP_TRY(hipSetDevice(r->ctx[k]->dom.device));
     HIP_TRY(hipStreamWaitEvent(r->ctx[k]->stream, r->unpacked[k], 0));
-    // a neighbour must not re-pack (overwrite its send buffers) before my copies of them are done
+    // a neighbour must not overwrite the planes I copy from before my copies of them are done
     HIP_TRY(hipStreamWaitEvent(r->ctx[k]->stream, r->unpacked[(k + 1) % n], 0));
     HIP_TRY(hipStreamWaitEvent(r->ctx[k]->stream, r->unpacked[(k + n - 1) % n], 0));
   }
@@ -949,17 +974,17 @@ int bflbm_ring_create(const bflbm_params* p, const int n[3], int nslabs, const i
       if (e == hipSuccess) e = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&e2, hipEventDisableTiming);
       r->comm.push_back(st); r->packed.push_back(e1); r->unpacked.push_back(e2);
-      for (int side = 0; side < 2; ++side) {
-        double *s1 = nullptr, *r1 = nullptr;
-        if (e == hipSuccess) e = hipMalloc((void**)&s1, b);
-        if (e == hipSuccess) e = hipMalloc((void**)&r1, b);
-        r->send[side].push_back(s1); r->recv[side].push_back(r1);
-      }
       // peer access to the ring neighbours' send buffers (a no-op when they share the device)
-      for (int nb : { (k + 1) % nslabs, (k + nslabs - 1) % nslabs }) {
-        const int pd = r->ctx[nb]->dom.device;
-        if (pd != r->ctx[k]->dom.device) { int can = 0; hipDeviceCanAccessPeer(&can, r->ctx[k]->dom.device, pd); if (can) hipDeviceEnablePeerAccess(pd, 0); (void)hipGetLastError(); }
+      std::array<bool, 2> ok = {false, false};
+      const int nbs[2] = { (k + nslabs - 1) % nslabs, (k + 1) % nslabs };       // lower, upper
+      for (int sd = 0; sd < 2; ++sd) {
+        const int pd = r->ctx[nbs[sd]]->dom.device;
+        if (pd == r->ctx[k]->dom.device) { ok[sd] = true; continue; }
+        int can = 0; hipDeviceCanAccessPeer(&can, r->ctx[k]->dom.device, pd);
+        if (can) { const hipError_t pe = hipDeviceEnablePeerAccess(pd, 0); ok[sd] = (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled); }
+        (void)hipGetLastError();
       }
+      r->peer_ok.push_back(ok);
     }
     if (e != hipSuccess) { fail("bflbm_ring_create: %s", hipGetErrorString(e)); bflbm_ring_destroy(r); return 1; }
   }
@@ -974,10 +999,6 @@ int bflbm_ring_destroy(bflbm_ring* r) {
     if (k < r->comm.size() && r->comm[k]) { hipStreamSynchronize(r->comm[k]); hipStreamDestroy(r->comm[k]); }
     if (k < r->packed.size() && r->packed[k]) hipEventDestroy(r->packed[k]);
     if (k < r->unpacked.size() && r->unpacked[k]) hipEventDestroy(r->unpacked[k]);
-    for (int side = 0; side < 2; ++side) {
-      if (k < r->send[side].size() && r->send[side][k]) hipFree(r->send[side][k]);
-      if (k < r->recv[side].size() && r->recv[side][k]) hipFree(r->recv[side][k]);
-    }
     bflbm_destroy(r->ctx[k]);
   }
   delete r;
@@ -1065,8 +1086,10 @@ int bflbm_ring_step(bflbm_ring* r, int nsteps) {
   for (int s = 0; s < nsteps; ++s) {
     if (ring_prepare_ref(r)) return 1;
     for (bflbm_ctx* c : r->ctx) if (bflbm_step_boundary(c)) return 1;
-    if (ring_exchange(r, BFLBM_HALO_NEXT)) return 1;       // comm streams: copies + unpack ...
-    for (bflbm_ctx* c : r->ctx) if (bflbm_step_interior(c)) return 1;   // ... while the main streams sweep the interior
+    if (ring_mark(r)) return 1;                             // boundary planes final: the neighbours may copy them
+    for (bflbm_ctx* c : r->ctx) if (bflbm_step_interior(c)) return 1;   // main streams sweep the interior ...
+    if (ring_copy(r, BFLBM_HALO_NEXT)) return 1;            // ... while the comm streams move the faces (enqueued after the
+                                                            // interior launches so that the 76 copy calls per slab delay nothing)
     if (ring_join(r)) return 1;
     for (bflbm_ctx* c : r->ctx) if (bflbm_step_finish(c)) return 1;
   }

@@ -454,6 +454,17 @@ __global__ void __launch_bounds__(256) k_halo_unpack(double* __restrict__ S, con
   S[(long long)T.comp[e]*G.vol + (long long)T.plane[e]*G.plane + s] = buf[(long long)e*G.plane + s];
 }
 
+// one face without staging: entry e of the halo table is a contiguous plane in the source slab (table Ts, possibly the
+// memory of a peer GPU) and in the destination slab (table Td)
+__global__ void __launch_bounds__(256) k_halo_pull(double* __restrict__ D, const double* __restrict__ Ssrc, long long plane,
+                                                   long long dvol, long long svol, HaloTable Td, HaloTable Ts) {
+  const long long s = ((long long)blockIdx.x*blockDim.x + threadIdx.x) * 2;      // 16 bytes per lane
+  if (s >= plane) return;
+  const int e = blockIdx.y;
+  const double2 v = *reinterpret_cast<const double2*>(Ssrc + (long long)Ts.comp[e]*svol + (long long)Ts.plane[e]*plane + s);
+  *reinterpret_cast<double2*>(D + (long long)Td.comp[e]*dvol + (long long)Td.plane[e]*plane + s) = v;
+}
+
 // ---- slab reductions (deterministic: per-block partials, summed on the host in block order)
 // out[b][0..5] = sum rho, sum phi, sum rho*i, sum rho*j, sum rho*k (global k), 0
 __global__ void __launch_bounds__(256) k_reduce(const double* __restrict__ rho, const double* __restrict__ phi,

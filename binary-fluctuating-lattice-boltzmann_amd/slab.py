@@ -88,6 +88,8 @@ class SlabLattice(_Protocol):
         self.upper = (self.rank + 1) % self.world
         self._bufs = None
         self._work = None
+        # what crosses one face per step: 38 component planes (14 + 14 of the nearest plane, 5 + 5 of the second)
+        self.halo_bytes_per_face = int(engine.halo_bytes(_lib.HALO_STATE)) if self.world > 1 else 0
         # RCCL orders its work after the current stream by itself; host-driven backends (gloo) read
         # the send buffers from the host side, so the pack kernels must have completed first.
         self._host_sync = dist.get_backend(group) != "nccl"
