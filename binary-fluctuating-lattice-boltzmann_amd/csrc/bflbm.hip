@@ -16,6 +16,9 @@
 #include "bflbm_kernels.h"
 #include "bflbm_fused.h"
 #include "bflbm_handover.h"
+#ifdef BFLBM_CALIBRATION
+#include "../../tools/calibration_kernels.h"
+#endif
 
 namespace {
 
@@ -360,6 +363,7 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   // allocation, below) gives 0: 6780, 1040: 6870-6940, 65552: 6935-7000, 262160: 6970, 1048592: 6730 MLUPS
   // -> 65552 doubles = 512 KB + one line (BFLBM_PAD = doubles, tuning override).
   static const long long pad = [] { const char* e = getenv("BFLBM_PAD"); return e ? atoll(e) : 1040LL; }();
+  if (pad < 0 || (pad & 1)) { delete c; return fail("BFLBM_PAD must be a non-negative even number of doubles"); }
   G.vol = G.plane * G.nzs + pad;
   const size_t sbytes = (size_t)2 * Q * G.vol * sizeof(double);
   const size_t fbytes = (size_t)G.vol * sizeof(double);
@@ -370,6 +374,7 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   // box); inside one allocation it is reproducible to 0.3 %, 520 doubles is a bad displacement (-4 %),
   // anything from 25k to 1M doubles is equally good (BFLBM_AB_OFF = doubles, tuning override).
   static const long long ab_off = [] { const char* e = getenv("BFLBM_AB_OFF"); return e ? atoll(e) : 33280LL; }();
+  if (ab_off < 0 || (ab_off & 1)) { delete c; return fail("BFLBM_AB_OFF must be a non-negative even number of doubles"); }
   e = hipMalloc((void**)&c->S[0], 2 * sbytes + (size_t)ab_off * sizeof(double));
   if (e == hipSuccess) c->S[1] = c->S[0] + (size_t)2 * Q * G.vol + ab_off;
   if (e == hipSuccess) e = hipMalloc((void**)&c->rho, fbytes);
@@ -839,8 +844,10 @@ int bflbm_debug_time_kernel(bflbm_ctx* c, int which, int reps, float* ms) {
     if (r == 0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (which == 0) hipLaunchKernelGGL(k_pull, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
     else if (which == 1) hipLaunchKernelGGL(k_density, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->rho, c->phi, c->G, own_lo(c));
+#ifdef BFLBM_CALIBRATION
     else if (which == 3 && c->G.pitch == c->G.nx) hipLaunchKernelGGL(k_pull2, dim3((unsigned)((c->G.plane / 2 + 255) / 256), (unsigned)c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
     else if (which == 4 && c->G.zwrap && c->G.pitch == c->G.nx) hipLaunchKernelGGL(k_pull_rows, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[c->cur], c->S[1 - c->cur], c->G, own_lo(c));
+#endif
     else if (which == 2) HIP_TRY(hipMemcpyAsync(c->S[1 - c->cur], c->S[c->cur], sbytes, hipMemcpyDeviceToDevice, c->stream));
     else return fail("unknown diagnostic kernel %d", which);
   }
@@ -854,13 +861,6 @@ int bflbm_debug_time_kernel(bflbm_ctx* c, int which, int reps, float* ms) {
   return 0;
 }
 
-#ifdef BFLBM_STAMP
-extern "C" int bflbm_debug_stamps(unsigned long long* out, int max_waves) {   // diagnostic builds only
-  int n = g_stamp_n < max_waves ? g_stamp_n : max_waves;
-  if (g_stamp_buf && n > 0) hipMemcpy(out, g_stamp_buf, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-  return n;
-}
-#endif
 
 int bflbm_device_bytes(const bflbm_ctx* c, size_t* bytes) {
   if (!c || !bytes) return fail("null argument");

@@ -33,7 +33,6 @@ struct FusedGrid {
   int total;           // ncols*nchunks workgroups
   int per_xcd;         // ceil(total/8)
   int sx;              // strip width (tiles in x) of the column order, see fused_map
-  unsigned long long* dbg;   // BFLBM_STAMP diagnostic builds only: per-workgroup phase cycle sums
 };
 
 // Workgroup -> (column, chunk).  Workgroups b and b+8 share an XCD (round-robin dispatch), so give
@@ -61,15 +60,6 @@ __device__ __forceinline__ bool fused_map(const FusedGrid& F, int b, int& col, i
   return true;
 }
 
-#ifdef BFLBM_STAMP
-#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-  __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tacc[k] += t_ - tlast; tlast = t_; } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
-#ifndef BFLBM_ABL
-#define BFLBM_ABL 0   // ablation switches for timing experiments only (results become wrong)
-#endif
 
 // Tile geometry: TX x TY threads, one site each, tiles aligned to TX (row segments start on
 // 128-byte lines when TX is a multiple of 16).  rho,phi of the one-site ring around the tile are
@@ -83,7 +73,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   constexpr int LW = TX + 2;                     // LDS row length
   constexpr int LSZ = (TX + 2) * (TY + 2);
   constexpr int NW = TX * TY / 64;
-  static_assert((BFLBM_ABL & 1) || (NW % 2 == 0 && (2 * (TX + 2) + 2 * TY) <= 64 * (NW / 2)), "ring tasks of one fluid must fit one per lane of half the waves");
+  static_assert(NW % 2 == 0 && (2 * (TX + 2) + 2 * TY) <= 64 * (NW / 2), "ring tasks of one fluid must fit one per lane of half the waves");
   __shared__ double rp[4][2][LSZ];               // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
   __shared__ double gl[Q][TX * TY];              // g populations of the previous plane
   __shared__ float ntab[MODE == 1 ? BFLBM_NORMAL_TABLE_FLOATS : 4];
@@ -118,7 +108,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hfl = wv / (NW / 2);
   const int task = (wv % (NW / 2)) * nper + lane;
-  const bool has_task = (BFLBM_ABL & 1) ? false : (lane < nper && task < nring);
+  const bool has_task = lane < nper && task < nring;
   int hlx = 0, hly = 0;                          // LDS coordinates of the ring site
   if (has_task) {
     const int r = task;
@@ -150,14 +140,9 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #pragma unroll
   for (int i = 0; i < Q; ++i) pf[i] = 0.;
 
-#ifdef BFLBM_STAMP
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = __builtin_amdgcn_s_memtime();
-#endif
   int it = 0;
   for (int q = qa - 1; q <= qb; ++q, ++it) {
     const int slot = it & 3;
-    STAMP(5);
     // wave-uniform plane bases: every load below is  (SGPR base) + (32-bit lane offset)
     const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
                                          S + (long long)wrapp(q + 1) * G.plane };
@@ -199,7 +184,6 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #pragma unroll
       for (int i = 0; i < Q; ++i) hv[i] = 0.;
     }
-    STAMP(0);                                   // loads issued
     // 2. densities of plane q into the ring slot.  The sums start from an opaque zero defined HERE: with a
     // literal 0.0 the compiler sinks the first addition (0.0 + f_0) into the load blocks above and waits
     // for the first load before it issues the rest.
@@ -212,9 +196,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
     // own sums first: their loads were issued first, the ring loads are still landing meanwhile
     if (loader) { rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg); }
     if (has_task) rp[slot][hfl][lhalo] = density(hv);
-    STAMP(1);                                   // data arrived, sums done
     __syncthreads();
-    STAMP(2);                                   // barrier
     // 3. collide plane q-1: f from registers, g streamed out of LDS while plane q's g takes its place
     const bool do_collide = (q - 1 >= qa) && (q - 1 < qb) && interior;
     double mg[Q], jg[3];
@@ -262,10 +244,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
       double* __restrict__ Dp = D + (long long)pc * G.plane;
       unsigned o = yo[1] + xo[1];
       asm volatile("" : "+v"(o));
-      if (BFLBM_ABL & 2) {
-#pragma unroll
-        for (int i = 0; i < Q; ++i) { st(Dp + (long long)i * G.vol, o, mf[i] + grad_rho[0]); st(Dp + (long long)(i + Q) * G.vol, o, mg[i] + grad_phi[1]); }
-      } else {
+      {
         SiteHydro Hy;
         SiteRecip R;
         d_site_recips(P, r, ph, R);
@@ -310,17 +289,9 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
         }
       }
     }
-    STAMP(3);                                   // collide + stores issued
 #pragma unroll
     for (int i = 0; i < Q; ++i) pf[i] = cf[i];
   }
-#ifdef BFLBM_STAMP
-  if (F.dbg && (tid & 63) == 0) {
-    unsigned long long* o = F.dbg + ((long long)blockIdx.x * (TX * TY / 64) + (tid >> 6)) * 8;
-    for (int k = 0; k < 6; ++k) o[k] = tacc[k];
-    o[6] = (unsigned long long)it; o[7] = __builtin_amdgcn_s_memtime();
-  }
-#endif
 }
 
 #ifndef BFLBM_FUSED_TX
@@ -330,10 +301,6 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #define BFLBM_FUSED_TY 8
 #endif
 
-#ifdef BFLBM_STAMP
-static unsigned long long* g_stamp_buf = nullptr;
-static int g_stamp_n = 0;
-#endif
 static int g_fused_ncu = 0;     // compute units of the device (set at context creation)
 // returns non-zero on launch failure
 static inline int fused_launch(const double* S, double* D, const double* injf, const double* injg,
@@ -385,10 +352,6 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   F.total = F.ncols * F.nchunks;
   F.per_xcd = (F.total + 7) / 8;
   { static const int sx_env = [] { const char* e = getenv("BFLBM_MAP_SX"); return e ? atoi(e) : 0; }(); F.sx = sx_env > 0 ? sx_env : std::min(F.ntx, 4); }   // strips of 4 tiles: +2 % at 512^3 (ntx = 8), identical at 256^3
-  F.dbg = nullptr;
-#ifdef BFLBM_STAMP
-  { static unsigned long long* dbuf = nullptr; if (!dbuf) hipMalloc(&dbuf, 8192 * 16 * 8 * sizeof(unsigned long long)); F.dbg = dbuf; g_stamp_buf = dbuf; g_stamp_n = F.per_xcd * 8 * (TX * TY / 64); }
-#endif
   dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
   if (mode == 2)      hipLaunchKernelGGL((k_fused<TX, TY, 2>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
   else if (mode == 1) hipLaunchKernelGGL((k_fused<TX, TY, 1>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);

@@ -473,7 +473,6 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
   F.total = F.ncols * F.nchunks;
   F.per_xcd = (F.total + 7) / 8;
   { static const int sx_env = [] { const char* e = getenv("BFLBM_MAP_SX"); return e ? atoi(e) : 0; }(); F.sx = sx_env > 0 ? sx_env : F.ntx; }
-  F.dbg = nullptr;
   sig_out.pa = pa; sig_out.pb = pb; sig_out.lz = F.lz; sig_out.nchunks = F.nchunks; sig_out.cstride = F.cstride; sig_out.step = steps;
   HoGrid Hg;
   Hg.fin = fin; Hg.fout = fout;

@@ -175,6 +175,7 @@ int bflbm_sf_accumulate(bflbm_sf* s, int lb_hydrovars, int reset) {
   if (lb_hydrovars && s->nvar_fields > BFLBM_NHYDROBAR) return fail("bflbm_sf_accumulate: pair variables outside hydrovsbar");
   if (reset && bflbm_sf_reset(s)) return 1;
   HIP_TRY(hipSetDevice(c->dom.device));
+  g_fft.set_stream(s->plan, c->stream);              // the context's stream may have been replaced (bflbm_set_stream) since the plan was made
   if (!lb_hydrovars && ensure_density(c)) return 1;
   if (!lb_hydrovars && prepare_ref(c)) return 1;
   const RefState Rf = ref_state(c);

@@ -42,7 +42,9 @@ def concatenate(root, step, ndigits=7):
 
 
 def chop_boxes(n, max_grid_size):
-    """BoxArray(domain).maxSize(max_grid_size): boxes in the order z-slowest, x-fastest."""
+    """BoxArray(domain).maxSize(max_grid_size): boxes in the order z-slowest, x-fastest.  When a size is not a
+    multiple of max_grid_size the last box of a direction is the remainder here, whereas BoxArray::maxSize cuts
+    near-equal pieces; no fixture of the reference covers that case (parity unpinned), its drivers use nx/2."""
     nx, ny, nz = n
     m = max_grid_size if max_grid_size else max(n)
     boxes = []
@@ -94,7 +96,8 @@ def write_plotfile(name, data, names, time=0.0, step=0, max_grid_size=None,
             flat = sub.reshape(ncomp, -1)
             mins.append(flat.min(axis=1))
             maxs.append(flat.max(axis=1))
-    c = ["1", "0", str(ncomp), "0", f"({len(boxes)} 0"] + [_box_str(lo, hi) for lo, hi in boxes] + [")", str(len(boxes))]
+    # VisMF header: version 1, how = 1 (VisMF::NFiles, AMReX's default for a shared Cell_D_ file), ncomp, ngrow
+    c = ["1", "1", str(ncomp), "0", f"({len(boxes)} 0"] + [_box_str(lo, hi) for lo, hi in boxes] + [")", str(len(boxes))]
     c += [f"FabOnDisk: Cell_D_00000 {o}" for o in offsets]
     # + 0.0: a minimum of -0.0 prints as 0 (min/max of mixed signed zeros is implementation-defined)
     c += ["", f"{len(boxes)},{ncomp}"] + [",".join(_real(v + 0.0) for v in m) + "," for m in mins]

@@ -85,7 +85,7 @@ def main(argv=None):
     ap.add_argument("--plot-sf-window", type=int, default=0)               # :99
     ap.add_argument("--out-sf-step", type=int, default=100)                # :100
     ap.add_argument("--step-continue", type=int, default=0)                # :80
-    ap.add_argument("--continue-from-nonfluct", action="store_true", default=True)   # :84
+    ap.add_argument("--continue-from-nonfluct", action=argparse.BooleanOptionalAction, default=True)   # :84 (--no-continue-from-nonfluct: restart from a kBT > 0 checkpoint, :259)
     ap.add_argument("--restart", action="store_true", help="if_continue_from_last_frame (:248)")
     ap.add_argument("--radius", type=float, default=0.2)                   # :110
     ap.add_argument("--init-frac", type=float, default=0.5)                # :33
@@ -172,7 +172,11 @@ def main(argv=None):
     plot_sf = a.plot_sf_window if noise else 0                              # :102
     sf = None                                                               # :310
     if plot_sf > 0:
-        sf = pkg.structfact.DeviceStructFact(lbm, names) if a.sf_device else pkg.structfact.StructFact(names)
+        # STRUCT_LB_HYDROVARS accumulates hydrovsbar, whose components 9..14 are never written (LBM_binary.H:333-339)
+        # and which has no components 15..21: only the pairs inside its 9 defined components are formed
+        sf_names = names[:9] if a.lb_hydrovars else names
+        sf = (pkg.structfact.DeviceStructFact(lbm, sf_names, lb_hydrovars=a.lb_hydrovars) if a.sf_device
+              else pkg.structfact.StructFact(sf_names))
     sf_start = last - a.plot_sf_window                                      # :330
     out_step = a.step_continue + 2 * a.nsteps // 10 if noise else a.step_continue    # :89
     for step in range(a.step_continue + 1, last + 1):                       # :335-387

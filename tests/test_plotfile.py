@@ -32,7 +32,7 @@ def test_on_disk_layout(pkg, tmp_path):
     assert head[12].split() == ["0.25", "0.25", "0.25"]
     assert head[15] == "0 8 1" and head[-2] == "Level_0/Cell"
     cell_h = open(os.path.join(name, "Level_0", "Cell_H")).read().split("\n")
-    assert cell_h[:5] == ["1", "0", "2", "0", "(8 0"]
+    assert cell_h[:5] == ["1", "1", "2", "0", "(8 0"]     # version, how = VisMF::NFiles, ncomp, ngrow
     assert cell_h[5] == "((0,0,0) (1,1,1) (0,0,0))"
     fod = [ln for ln in cell_h if ln.startswith("FabOnDisk: Cell_D_00000 ")]
     assert len(fod) == 8 and fod[0].endswith(" 0")
