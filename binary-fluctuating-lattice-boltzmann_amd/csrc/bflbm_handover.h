@@ -332,49 +332,32 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       const int wb = it & 1;
       const double zn[Q] = {0.};
       // sorts the 19 outputs of one fluid by destination and advances the z pipelines (see the header comment)
-      // moments -> populations (same operations as d_populations, LBM_d3q19.H:167-247), issued in stages: a
-      // group of three populations that share a destination (dy,dz) is stored and folded into its x bucket
-      // before the next group is formed, so that the 19 outputs are never live together (register budget)
+      // moments -> populations from the same terms as d_populations; a group of three populations that share a
+      // destination (dy,dz) is stored and folded into its x bucket right after it is formed
       auto finish_fluid = [&](const double (&mom)[Q], const int k) {
-        double m[Q];
-        m[0]  = d_div9(mom[0])  * 0.25;   m[1]  = d_div3(mom[1])  * 0.25;   m[2]  = d_div3(mom[2])  * 0.25;
-        m[3]  = d_div3(mom[3])  * 0.25;   m[4]  = d_div3(mom[4])  * 0.125;  m[5]  = d_div3(mom[5])  * 0.0625;
-        m[6]  = mom[6]  * 0.0625;         m[7]  = mom[7]  * 0.25;           m[8]  = mom[8]  * 0.25;
-        m[9]  = mom[9]  * 0.25;           m[10] = d_div3(mom[10]) * 0.125;  m[11] = d_div3(mom[11]) * 0.125;
-        m[12] = d_div3(mom[12]) * 0.125;  m[13] = mom[13] * 0.125;          m[14] = mom[14] * 0.125;
-        m[15] = mom[15] * 0.125;          m[16] = d_div9(mom[16]) * 0.125;  m[17] = d_div3(mom[17]) * 0.0625;
-        m[18] = mom[18] * 0.0625;
-        const double mc0 = 12.*(m[0] - m[4] + m[16]);
-        const double mc1 =  2.*(m[0] - 2.*m[16]);
-        const double mc2 = m[0] + m[4] + m[16];
-        const double mx1 = 2.*(m[1] - 2.*m[10]), my1 = 2.*(m[2] - 2.*m[11]), mz1 = 2.*(m[3] - 2.*m[12]);
-        const double mx2 = m[1] + m[10] + m[13], my2 = m[2] + m[11] + m[14], mz2 = m[3] + m[12] + m[15];
-        const double mx3 = m[1] + m[10] - m[13], my3 = m[2] + m[11] - m[14], mz3 = m[3] + m[12] - m[15];
-        const double mxx1 = mc1 + 4.*(m[5] - m[17]);
-        const double myy1 = mc1 - 2.*(m[5] - m[6]) + 2.*(m[17] - m[18]);
-        const double mzz1 = mc1 - 2.*(m[5] + m[6]) + 2.*(m[17] + m[18]);
-        const double mxy2 = mc2 + (m[5] + m[6]) + (m[17] + m[18]);
-        const double mxz2 = mc2 + (m[5] - m[6]) + (m[17] - m[18]);
-        const double myz2 = mc2 - 2.*(m[5] + m[17]);
-        const double mxy = m[7], myz = m[8], mxz = m[9];
+        PopTerms T;
+        d_population_terms(mom, T);
         double* __restrict__ Dk = Dp + (long long)(k * Q) * G.vol;
         auto put = [&](int i, double v) { st(Dk + (long long)i * G.vol, o, v); };
-        const double o0 = mc0, o1 = mxx1 + mx1, o2 = mxx1 - mx1;
+        auto diag = [&](int g, int j) {          // population j of plane g (d_populations)
+          return j == 0 ? T.B[g] + T.p[g] + T.q[g] + T.r[g] : j == 1 ? T.B[g] - T.p[g] - T.q[g] + T.r[g]
+               : j == 2 ? T.B[g] + T.p[g] - T.q[g] - T.r[g] : T.B[g] - T.p[g] + T.q[g] - T.r[g]; };
+        const double o0 = T.rest, o1 = T.E[0] + T.O[0], o2 = T.E[0] - T.O[0];
         put(0, o0); put(1, o1); put(2, o2);
         const double x00 = o0 + ho_shr(o1) + ho_shl(o2);
-        const double o3 = myy1 + my1, o7 = mxy2 + mx2 + my3 + mxy, o10 = mxy2 - mx2 + my3 - mxy;
+        const double o3 = T.E[1] + T.O[1], o7 = diag(0, 0), o10 = diag(0, 3);
         put(3, o3); put(7, o7); put(10, o10);
         const double xp0 = o3 + ho_shr(o7) + ho_shl(o10);
-        const double o4 = myy1 - my1, o9 = mxy2 + mx2 - my3 - mxy, o8 = mxy2 - mx2 - my3 + mxy;
+        const double o4 = T.E[1] - T.O[1], o9 = diag(0, 2), o8 = diag(0, 1);
         put(4, o4); put(9, o9); put(8, o8);
         const double xm0 = o4 + ho_shr(o9) + ho_shl(o8);
-        const double o5 = mzz1 + mz1, o15 = mxz2 + mz2 + mx3 + mxz, o18 = mxz2 + mz2 - mx3 - mxz;
+        const double o5 = T.E[2] + T.O[2], o15 = diag(2, 0), o18 = diag(2, 2);
         put(5, o5); put(15, o15); put(18, o18);
         const double x0p = o5 + ho_shr(o15) + ho_shl(o18);
-        const double o6 = mzz1 - mz1, o17 = mxz2 - mz2 + mx3 - mxz, o16 = mxz2 - mz2 - mx3 + mxz;
+        const double o6 = T.E[2] - T.O[2], o17 = diag(2, 3), o16 = diag(2, 1);
         put(6, o6); put(17, o17); put(16, o16);
         const double x0m = o6 + ho_shr(o17) + ho_shl(o16);
-        const double o11 = myz2 + my2 + mz3 + myz, o12 = myz2 - my2 - mz3 + myz, o13 = myz2 + my2 - mz3 - myz, o14 = myz2 - my2 + mz3 - myz;
+        const double o11 = diag(1, 0), o12 = diag(1, 1), o13 = diag(1, 2), o14 = diag(1, 3);
         put(11, o11); put(12, o12); put(13, o13); put(14, o14);
         // what leaves the tile in x (column lanes only; side_x picks the lane's outward direction)
         const double oxp = side_x ? o15 : o18, ox0 = side_x ? o1 : o2, oxm = side_x ? o17 : o16, oyp = side_x ? o7 : o10, oym = side_x ? o9 : o8;

@@ -52,13 +52,13 @@ struct DevParams {
 // |eps| <= 2^-53, i.e. within 2^-52 ulp of x/d, far inside the 1/18 ulp margin, so the final
 // FMA rounding returns RN(x/d).  Division by 36, 12, 24, 48, 72 (LBM_d3q19.H:175-193) is one of
 // these followed by an exact power-of-two scaling.  tools/div_probe.hip checks 2^32 samples.
-__device__ __forceinline__ double d_div3(double x) {
+BFLBM_HD double d_div3(double x) {
   const double y = 0x1.5555555555555p-2;
   const double q = x * y;
   const double r = __builtin_fma(-3.0, q, x);
   return __builtin_fma(r, y, q);
 }
-__device__ __forceinline__ double d_div9(double x) {
+BFLBM_HD double d_div9(double x) {
   const double y = 0x1.c71c71c71c71cp-4;
   const double q = x * y;
   const double r = __builtin_fma(-9.0, q, x);
@@ -91,58 +91,63 @@ __device__ __forceinline__ void d_site_recips(const DevParams& P, double rho, do
   R.rho = d_recip(rho); R.phi = d_recip(phi); R.tot = d_recip(rho + phi); R.cs4 = d_recip(P.cs4);
 }
 
-// populations -> moments (LBM_d3q19.H:100-156)
-__device__ __forceinline__ void d_moments(const double (&fs)[Q], double (&m)[Q]) {
-  double f;
-  double mc0, mc1, mc2;
-  double mx1, my1, mz1, mx2, my2, mz2, mx3, my3, mz3;
-  double mxy, mxz, myz, mxx1, myy1, mzz1, mxx2, myy2, mzz2;
-  f = fs[0];  mc0 = f;
-  f = fs[1];  mx1 = f;  mxx1 = f;
-  f = fs[2];  mx1 -= f; mxx1 += f;
-  f = fs[3];  my1 = f;  myy1 = f;
-  f = fs[4];  my1 -= f; myy1 += f;
-  f = fs[5];  mz1 = f;  mzz1 = f;
-  f = fs[6];  mz1 -= f; mzz1 += f;
-  f = fs[7];  mx2 = f;  my3 = f;  mxy = f;  mxx2 = f;
-  f = fs[8];  mx2 -= f; my3 -= f; mxy += f; mxx2 += f;
-  f = fs[9];  mx2 += f; my3 -= f; mxy -= f; mxx2 += f;
-  f = fs[10]; mx2 -= f; my3 += f; mxy -= f; mxx2 += f;
-  f = fs[11]; my2 = f;  mz3 = f;  myz = f;  myy2 = f;
-  f = fs[12]; my2 -= f; mz3 -= f; myz += f; myy2 += f;
-  f = fs[13]; my2 += f; mz3 -= f; myz -= f; myy2 += f;
-  f = fs[14]; my2 -= f; mz3 += f; myz -= f; myy2 += f;
-  f = fs[15]; mz2 = f;  mx3 = f;  mxz = f;  mzz2 = f;
-  f = fs[16]; mz2 -= f; mx3 -= f; mxz += f; mzz2 += f;
-  f = fs[17]; mz2 -= f; mx3 += f; mxz -= f; mzz2 += f;
-  f = fs[18]; mz2 += f; mx3 -= f; mxz -= f; mzz2 += f;
-  mc1 = mxx1 + myy1 + mzz1;
-  mc2 = mxx2 + myy2 + mzz2;
-  m[0]  = mc0 + mc1 + mc2;
-  m[1]  = mx1 + mx2 + mx3;
-  m[2]  = my1 + my2 + my3;
-  m[3]  = mz1 + mz2 + mz3;
-  m[4]  = mc2 - mc0;
-  m[5]  = 3.*mxx1 - mc1 + mc2 - 3.*myy2;
-  m[6]  = myy1 - mzz1 + mxx2 - mzz2;
-  m[7]  = mxy;
-  m[8]  = myz;
-  m[9]  = mxz;
-  m[10] = m[1] - 3.*mx1;
-  m[11] = m[2] - 3.*my1;
-  m[12] = m[3] - 3.*mz1;
-  m[13] = mx2 - mx3;
-  m[14] = my2 - my3;
-  m[15] = mz2 - mz3;
-  m[16] = m[0] - 3.*mc1;
-  m[17] = mc1 - 3.*mxx1 + mc2 - 3.*myy2;
-  m[18] = mzz1 - myy1 + mxx2 - mzz2;
+// ---- the 19x19 moment transform (LBM_d3q19.H:100-156 and its inverse :167-247), in this project's own terms.
+// The velocity set is one rest population, three AXES with a (+,-) pair each (1,2 | 3,4 | 5,6) and three coordinate
+// PLANES with four diagonal populations each (xy 7..10, yz 11..14, xz 15..18).  A pair enters the moments through
+// its sum and difference; a plane's quad q0..q3 through four signed sums, accumulated left to right:
+//   u = q0 - q1 + q2 - q3,  v = q0 - q1 - q2 + q3,  w = q0 + q1 - q2 - q3,  t = q0 + q1 + q2 + q3.
+// Which Cartesian component u and v carry follows from the plane's velocities (table in d_moments).  Every
+// accumulator receives its terms in increasing population index and the combinations below keep the association
+// of the reference's expressions, so the doubles equal the reference's; tests check it against the oracle.
+struct Quad { double u, v, w, t; };
+BFLBM_HD Quad d_quad(double q0, double q1, double q2, double q3) {
+  Quad r;
+  r.u = q0; r.v = q0; r.w = q0; r.t = q0;
+  r.u -= q1; r.v -= q1; r.w += q1; r.t += q1;
+  r.u += q2; r.v -= q2; r.w -= q2; r.t += q2;
+  r.u -= q3; r.v += q3; r.w -= q3; r.t += q3;
+  return r;
 }
 
-// moments -> populations (LBM_d3q19.H:167-247)
-__device__ __forceinline__ void d_populations(const double (&mom)[Q], double (&f)[Q]) {
+// populations -> moments
+BFLBM_HD void d_moments(const double (&fs)[Q], double (&m)[Q]) {
+  double dif[3], sum[3];                       // per axis: f(+) - f(-), f(+) + f(-)
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { dif[a] = fs[1 + 2*a]; sum[a] = fs[1 + 2*a]; dif[a] -= fs[2 + 2*a]; sum[a] += fs[2 + 2*a]; }
+  const Quad xy = d_quad(fs[7], fs[8], fs[9], fs[10]);      // u: x-momentum, v: y-momentum
+  const Quad yz = d_quad(fs[11], fs[12], fs[13], fs[14]);   // u: y-momentum, v: z-momentum
+  const Quad xz = d_quad(fs[15], fs[16], fs[17], fs[18]);   // u: x-momentum, v: z-momentum
+  const double rest = fs[0];
+  const double shell1 = sum[0] + sum[1] + sum[2];           // populations of speed 1
+  const double shell2 = xy.t + yz.t + xz.t;                 // populations of speed sqrt 2
+  m[0]  = rest + shell1 + shell2;
+  m[1]  = dif[0] + xy.u + xz.u;
+  m[2]  = dif[1] + yz.u + xy.v;
+  m[3]  = dif[2] + xz.v + yz.v;
+  m[4]  = shell2 - rest;
+  m[5]  = 3.*sum[0] - shell1 + shell2 - 3.*yz.t;
+  m[6]  = sum[1] - sum[2] + xy.t - xz.t;
+  m[7]  = xy.w;
+  m[8]  = yz.w;
+  m[9]  = xz.w;
+  m[10] = m[1] - 3.*dif[0];
+  m[11] = m[2] - 3.*dif[1];
+  m[12] = m[3] - 3.*dif[2];
+  m[13] = xy.u - xz.u;
+  m[14] = yz.u - xy.v;
+  m[15] = xz.v - yz.v;
+  m[16] = m[0] - 3.*shell1;
+  m[17] = shell1 - 3.*sum[0] + shell2 - 3.*yz.t;
+  m[18] = sum[2] - sum[1] + xy.t - xz.t;
+}
+
+// moments -> populations.  PopTerms: what each group of populations is assembled from -- the rest population,
+// per axis the even part E and odd part O of its pair (f(+-) = E +- O), per plane the base B and the three signed
+// terms of its quad: q0 = B + p + q + r, q1 = B - p - q + r, q2 = B + p - q - r, q3 = B - p + q - r.
+struct PopTerms { double rest, E[3], O[3], B[3], p[3], q[3], r[3]; };   // planes: 0 xy, 1 yz, 2 xz
+BFLBM_HD void d_population_terms(const double (&mom)[Q], PopTerms& T) {
   double m[Q];
-  // mom/{36,12,12,12,24,48,16,4,4,4,24,24,24,8,8,8,72,48,16}, bit-identical to the divisions
+  // mom/{36,12,12,12,24,48,16,4,4,4,24,24,24,8,8,8,72,48,16} (the norms of the basis), bit-identical to the divisions
   m[0]  = d_div9(mom[0])  * 0.25;
   m[1]  = d_div3(mom[1])  * 0.25;
   m[2]  = d_div3(mom[2])  * 0.25;
@@ -162,48 +167,38 @@ __device__ __forceinline__ void d_populations(const double (&mom)[Q], double (&f
   m[16] = d_div9(mom[16]) * 0.125;
   m[17] = d_div3(mom[17]) * 0.0625;
   m[18] = mom[18] * 0.0625;
-
-  const double mc0 = 12.*(m[0] - m[4] + m[16]);
-  const double mc1 =  2.*(m[0] - 2.*m[16]);
-  const double mc2 = m[0] + m[4] + m[16];
-  const double mx1 = 2.*(m[1] - 2.*m[10]);
-  const double my1 = 2.*(m[2] - 2.*m[11]);
-  const double mz1 = 2.*(m[3] - 2.*m[12]);
-  const double mx2 = m[1] + m[10] + m[13];
-  const double my2 = m[2] + m[11] + m[14];
-  const double mz2 = m[3] + m[12] + m[15];
-  const double mx3 = m[1] + m[10] - m[13];
-  const double my3 = m[2] + m[11] - m[14];
-  const double mz3 = m[3] + m[12] - m[15];
-  const double mxx1 = mc1 + 4.*(m[5] - m[17]);
-  const double myy1 = mc1 - 2.*(m[5] - m[6]) + 2.*(m[17] - m[18]);
-  const double mzz1 = mc1 - 2.*(m[5] + m[6]) + 2.*(m[17] + m[18]);
-  const double mxy2 = mc2 + (m[5] + m[6]) + (m[17] + m[18]);
-  const double mxz2 = mc2 + (m[5] - m[6]) + (m[17] - m[18]);
-  const double myz2 = mc2 - 2.*(m[5] + m[17]);
-  const double mxy = m[7];
-  const double myz = m[8];
-  const double mxz = m[9];
-
-  f[0]  = mc0;
-  f[1]  = mxx1 + mx1;
-  f[2]  = mxx1 - mx1;
-  f[3]  = myy1 + my1;
-  f[4]  = myy1 - my1;
-  f[5]  = mzz1 + mz1;
-  f[6]  = mzz1 - mz1;
-  f[7]  = mxy2 + mx2 + my3 + mxy;
-  f[8]  = mxy2 - mx2 - my3 + mxy;
-  f[9]  = mxy2 + mx2 - my3 - mxy;
-  f[10] = mxy2 - mx2 + my3 - mxy;
-  f[11] = myz2 + my2 + mz3 + myz;
-  f[12] = myz2 - my2 - mz3 + myz;
-  f[13] = myz2 + my2 - mz3 - myz;
-  f[14] = myz2 - my2 + mz3 - myz;
-  f[15] = mxz2 + mz2 + mx3 + mxz;
-  f[16] = mxz2 - mz2 - mx3 + mxz;
-  f[17] = mxz2 - mz2 + mx3 - mxz;
-  f[18] = mxz2 + mz2 - mx3 - mxz;
+  T.rest = 12.*(m[0] - m[4] + m[16]);
+  const double e1 = 2.*(m[0] - 2.*m[16]);      // common even part of the speed-1 shell
+  const double e2 = m[0] + m[4] + m[16];       // common even part of the speed-sqrt-2 shell
+#pragma unroll
+  for (int a = 0; a < 3; ++a) T.O[a] = 2.*(m[1 + a] - 2.*m[10 + a]);
+  T.E[0] = e1 + 4.*(m[5] - m[17]);
+  T.E[1] = e1 - 2.*(m[5] - m[6]) + 2.*(m[17] - m[18]);
+  T.E[2] = e1 - 2.*(m[5] + m[6]) + 2.*(m[17] + m[18]);
+  T.B[0] = e2 + (m[5] + m[6]) + (m[17] + m[18]);
+  T.B[1] = e2 - 2.*(m[5] + m[17]);
+  T.B[2] = e2 + (m[5] - m[6]) + (m[17] - m[18]);
+  // momentum-like parts carried by the diagonals: (component sum) +- (ghost-vector part m13..15)
+  const double jx = m[1] + m[10], jy = m[2] + m[11], jz = m[3] + m[12];
+  T.p[0] = jx + m[13]; T.q[0] = jy - m[14]; T.r[0] = m[7];     // xy: x-part, y-part, shear
+  T.p[1] = jy + m[14]; T.q[1] = jz - m[15]; T.r[1] = m[8];     // yz: y-part, z-part, shear
+  T.p[2] = jz + m[15]; T.q[2] = jx - m[13]; T.r[2] = m[9];     // xz: z-part, x-part, shear
+}
+BFLBM_HD void d_populations(const double (&mom)[Q], double (&f)[Q]) {
+  PopTerms T;
+  d_population_terms(mom, T);
+  f[0] = T.rest;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { f[1 + 2*a] = T.E[a] + T.O[a]; f[2 + 2*a] = T.E[a] - T.O[a]; }
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const double q0 = T.B[g] + T.p[g] + T.q[g] + T.r[g];
+    const double q1 = T.B[g] - T.p[g] - T.q[g] + T.r[g];
+    const double q2 = T.B[g] + T.p[g] - T.q[g] - T.r[g];
+    const double q3 = T.B[g] - T.p[g] + T.q[g] - T.r[g];
+    // the xz plane lists (1,0,-1) before (-1,0,1) (LBM_d3q19.H:29-32): its third and fourth populations swap
+    f[7 + 4*g] = q0; f[8 + 4*g] = q1; f[9 + 4*g] = (g == 2) ? q3 : q2; f[10 + 4*g] = (g == 2) ? q2 : q3;
+  }
 }
 
 // rho = sum_i f_i in index order (hydrovars_bar_density, LBM_binary.H:320-328)

@@ -14,10 +14,17 @@
  *
  * PINNING: the reference cannot be compiled in this image (it needs AMReX, an
  * external library that is absent; writing stand-in headers is not allowed), and
- * it ships no golden vectors.  The oracle is pinned by the three reference
- * outputs recorded in SURVEY.md section 8c (8^3 stripe, 10 steps, produced by
- * the unmodified reference headers during the survey) -- see
- * tests/test_oracle_pins.py -- and by algebraic identities of the D3Q19 basis.
+ * it ships no golden vectors.  The oracle is pinned by outputs of the reference
+ * that its authors recorded in the notebooks under /root/reference: Flat_Interface.ipynb
+ * cell 4 (interface height 47.86628666 at 8x256x64, frame 2000), Surface_Tension.ipynb cells
+ * 13-19 (36 densities with 16 digits, force integrals, fitted radii and both Laplace-law surface
+ * tensions of nine 32^3 droplets at frame 20000) and Droplet_Fluctuation.ipynb cell 5 (centre of
+ * mass after 20000 steps) -- tests/test_oracle_pins.py, tests/test_gpu_notebook_surface_tension.py,
+ * tests/test_gpu_fullsize.py -- and by algebraic identities of the D3Q19 basis.  All of those runs
+ * used tau = 1/2 (full relaxation); for tau != 1/2 see DESIGN.md section 4 (parity unpinned by any
+ * recorded reference number; invariant tests instead).  The three numbers of SURVEY.md section 8c
+ * (8^3 stripe, 10 steps) are kept as a regression check only: they came from a survey-time build of the
+ * reference headers against stand-in AMReX types and pin nothing by themselves.
  * The Gaussian random stream (amrex::RandomNormal) is an un-vendored dependency:
  * noise parity with the reference is statistical only ("parity unpinned" at the
  * RNG boundary); this file defines the project's own counter-based stream.

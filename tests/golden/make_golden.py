@@ -3,8 +3,8 @@
 
 The reference itself cannot be run here (it needs AMReX, which is absent, and stand-in headers are
 not allowed), so these vectors are NOT reference outputs: they freeze the oracle at the commit where
-it reproduced, bit for bit, the three reference outputs recorded in SURVEY.md 8c
-(tests/test_oracle_pins.py::test_survey_recorded_reference_outputs).  The GPU path is compared with
+it reproduced the outputs the reference's authors recorded in their notebooks (Flat_Interface.ipynb cell 4,
+Surface_Tension.ipynb cells 13-19, Droplet_Fluctuation.ipynb cell 5; see oracle/bflbm_oracle.c).  The GPU path is compared with
 them on the GPU box, where /root/reference does not exist either.
 Compiler: gcc 11.4 -O3 -ffp-contract=off (oracle/Makefile).
 """

@@ -2,7 +2,7 @@
 """Writes tests/golden/oracle_golden_v2.npz: the fixture list of SURVEY.md 8c, from the CPU oracle.
 
 Like make_golden.py these are NOT reference outputs (the reference cannot be built here): they freeze
-the oracle at the commit where it reproduced the reference outputs recorded in SURVEY.md 8c bit for bit.
+the oracle at the commit where it reproduced the notebook outputs of the reference (oracle/bflbm_oracle.c).
   * trajectories  N in {8, 12, 16} x {stripe 0.5, droplet 0.3, mixture} x steps {1, 3, 10, 100}, kBT = 0:
     f, g, hydrovsbar[0..8], hydrovs[0..21] -- full arrays for N = 8, SHA-256 of the little-endian bytes for
     N = 12 and 16 (bit-exact comparisons need nothing more and the file stays small);

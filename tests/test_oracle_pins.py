@@ -1,9 +1,11 @@
-"""CPU tests of the oracle (oracle/bflbm_oracle.c): reference outputs recorded in SURVEY.md 8c,
+"""CPU tests of the oracle (oracle/bflbm_oracle.c): outputs of the reference recorded by its authors in
+the notebooks (Flat_Interface.ipynb cell 4 here; Surface_Tension and Droplet_Fluctuation in the GPU tests),
 algebraic identities of the D3Q19 basis, conservation laws, streaming indexing, noise statistics.
 
-The reference ships no executable tests or golden vectors and cannot be
-compiled here (AMReX absent), so the three numbers below -- produced by the unmodified reference
-headers during the survey -- are the bit-level pin of the whole deterministic path.
+The reference ships no executable tests or golden vectors and cannot be compiled here
+(AMReX absent).  The three SURVEY.md 8c numbers below came from a survey-time build of the reference headers
+against stand-in AMReX types: they are a regression check of the oracle, not a pin; the pins are the notebook
+outputs.
 """
 import ctypes
 
@@ -12,7 +14,7 @@ import pytest
 
 
 def test_survey_recorded_reference_outputs(ob):
-    """8^3 stripe (frac 0.5, header defaults), 10 steps, g++ -O2 without FMA."""
+    """8^3 stripe (frac 0.5, header defaults), 10 steps, g++ -O2 without FMA (regression check)."""
     ref = ob.OracleLattice(8, 8, 8)
     ref.init_stripe(0.5)
     for _ in range(10):
@@ -26,8 +28,8 @@ def test_survey_recorded_reference_outputs(ob):
 
 
 def test_golden_fixture_matches_current_oracle(ob):
-    """tests/golden/*.npz were written by tests/golden/make_golden.py from this oracle at the commit
-    that matched the SURVEY pins; they guard against silent edits of the oracle."""
+    """tests/golden/*.npz were written by tests/golden/make_golden.py from this oracle at the commit that
+    reproduced the notebook outputs; they guard against silent edits of the oracle."""
     import os
     path = os.path.join(os.path.dirname(__file__), "golden", "oracle_trajectories.npz")
     g = np.load(path)
