@@ -349,3 +349,40 @@ def test_ref_state_shift_beyond_the_lattice_stays_in_range(ob):
     shift = [int(np.fmod(np.trunc(r), m)) for r, m in zip(rel, n)]
     rolled = np.roll(fld, shift=(shift[2], shift[1], shift[0]), axis=(0, 1, 2))   # value at x = fld[(x - s) mod n]
     np.testing.assert_allclose(noise_for(rel)[4] / np.sqrt(rolled), noise_for([0.3, 0.3, 0.3])[4] / np.sqrt(fld), rtol=1e-12)
+
+
+@pytest.mark.parametrize("tau_f,tau_g", [(0.8, 0.6), (1.0, 1.0), (1.5, 0.75)])
+def test_partial_relaxation_rate_of_every_mode(ob, tau_f, tau_g):
+    """tau != 1/2 (no recorded reference output exists there, see tests/relaxation_cases.py): a uniform perturbation
+    along moment a decays by exactly 1 - 1/(tau + 1/2) per step, per fluid (LBM_binary.H:504-511)."""
+    import relaxation_cases as rc
+    n = 4
+    for a in range(4, 19):
+        lat = ob.OracleLattice(n, n, n, params=ob.default_params(tau_f=tau_f, tau_g=tau_g, alpha0=2.0))
+        lat.f[:], lat.g[:] = rc.uniform_mode_state(ob, n, a)
+        lat.refresh()
+        prev = (rc.moment(ob, lat.f[:, 1, 2, 3], a), rc.moment(ob, lat.g[:, 1, 2, 3], a))
+        for _ in range(3):
+            lat.timestep()
+            cur = (rc.moment(ob, lat.f[:, 1, 2, 3], a), rc.moment(ob, lat.g[:, 1, 2, 3], a))
+            assert abs(cur[0] / prev[0] - (1.0 - 1.0 / (tau_f + 0.5))) < 1e-10, (a, cur, prev)
+            assert abs(cur[1] / prev[1] - (1.0 - 1.0 / (tau_g + 0.5))) < 1e-10, (a, cur, prev)
+            prev = cur
+
+
+@pytest.mark.parametrize("tau", [0.5, 0.8, 1.0])
+def test_shear_wave_decays_with_viscosity_cs2_tau(ob, tau):
+    """nu = cs2 tau (LBM_binary.H:504-505 tau_bar = tau + 1/2): transverse wave of wavelength 64."""
+    import relaxation_cases as rc
+    nx, ny, nz = 64, 4, 4
+    lat = ob.OracleLattice(nx, ny, nz, params=ob.default_params(tau_f=tau, tau_g=tau, alpha0=0.0))
+    lat.f[:], lat.g[:] = rc.shear_wave_state(ob, nx, ny, nz)
+    lat.refresh()
+    for _ in range(100):
+        lat.timestep()
+    a1 = rc.shear_amplitude(ob, lat.f, lat.g)
+    for _ in range(200):
+        lat.timestep()
+    a2 = rc.shear_amplitude(ob, lat.f, lat.g)
+    nu = -np.log(a2 / a1) / ((2 * np.pi / nx) ** 2 * 200)
+    assert abs(nu / (tau / 3.0) - 1.0) < 5e-3, nu
