@@ -11,11 +11,17 @@
 // LBM_SF_WINDOW=w [LBM_SF_STEP=s]: structure factors like main_run_job.cpp:301-310, :342-349, :50-54 --
 // FortStructure(hydrovs, 0) every s steps inside the last w steps, WritePlotFile with the last frame.
 //
+// LBM_RESTART_FROM=<plot_root> LBM_RESTART_STEP=<n>: the `if_continue_from_last_frame` branch of the live driver
+// (main_run_job.cpp:253-270): LoadSingleMultiFab of <plot_root>/f_checkpoint<n>, g_checkpoint<n> from DISK, then
+// LBM_init instead of the init dispatch.  LBM_EDIT_CHECK=1: after the run the driver scales fold on the host and calls
+// LBM_hydrovars_density(geom, fold, gold, hydrovsbar) -- the operator must evaluate the populations it is handed.
+//
 // Built a second time with -DUSE_REF_STATE (lbm_run_job_ref), like the reference's compile-time switch
 // (LBM_binary.H:12): the run then mirrors the noiseSwitch flow of main_run_job.cpp:216-235, :253-270 --
-// equilibrium fields into rho_eq/phi_eq/rhot_eq (here: the initial state's hydrovs 0, 1, 5 instead of
-// files), com_ref from update_com(rho_eq) (here moved by (2.6,-1.4,3.3) so that the lookup is shifted),
-// continuation through LBM_init, then the time loop.
+// equilibrium fields into rho_eq/phi_eq/rhot_eq (the initial state's hydrovs 0, 1, 5, or, with
+// LBM_EQ_FROM=<plot_root>, LoadSingleMultiFab of <plot_root>/equilibrium_rho, _phi, _rhot written by a kBT = 0 run of
+// this driver, and the populations of its checkpoints), com_ref from update_com(rho_eq) (moved by (2.6,-1.4,3.3) so
+// that the lookup is shifted), continuation through LBM_init, then the time loop.
 #include <algorithm>
 #include <array>
 #include <cctype>
@@ -67,6 +73,15 @@ int main(int argc, char* argv[]) {
   MultiFab fnoisevs(ba, nvel, nghost, domain), gnoisevs(ba, nvel, nghost, domain);
   std::vector<std::array<double, 3>> com_ref(3, {nx / 2., nx / 2., nx / 2.});   // :117-119
 
+  const char* restart_from = std::getenv("LBM_RESTART_FROM");
+  if (restart_from) {                                       // if_continue_from_last_frame, :253-270
+    const int rstep = std::getenv("LBM_RESTART_STEP") ? std::atoi(std::getenv("LBM_RESTART_STEP")) : 0;
+    MultiFab f_last_frame(ba, nvel, nghost, domain), g_last_frame(ba, nvel, nghost, domain);
+    std::printf("Loading in last frame checkpoint files....\n");
+    if (!bflbm::LoadSingleMultiFab(bflbm::Concatenate(std::string(restart_from) + "/f_checkpoint", rstep), f_last_frame) ||
+        !bflbm::LoadSingleMultiFab(bflbm::Concatenate(std::string(restart_from) + "/g_checkpoint", rstep), g_last_frame)) return 3;
+    LBM_init(geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs, f_last_frame, g_last_frame, rho_eq, phi_eq, rhot_eq, com_ref);
+  } else
   if (system == "mixture")      LBM_init_mixture(geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq);
   else if (system == "stripe")  LBM_init_stripe(0.5, geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq);
   else if (system == "droplet") LBM_init_droplet(0.2, geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq);
@@ -75,20 +90,31 @@ int main(int argc, char* argv[]) {
 #ifdef USE_REF_STATE
   {
     bflbm::materialize(geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs);
-    for (MFIter mfi(hydrovs); mfi.isValid(); ++mfi) {
-      const Box& v = mfi.validbox();
-      for (int z = v.smallEnd(2); z <= v.bigEnd(2); ++z) for (int y = v.smallEnd(1); y <= v.bigEnd(1); ++y) for (int x = v.smallEnd(0); x <= v.bigEnd(0); ++x) {
-        rho_eq[mfi](x, y, z, 0) = hydrovs[mfi](x, y, z, 0);
-        phi_eq[mfi](x, y, z, 0) = hydrovs[mfi](x, y, z, 1);
-        rhot_eq[mfi](x, y, z, 0) = hydrovs[mfi](x, y, z, 5);
+    MultiFab f0(ba, nvel, nghost, domain), g0(ba, nvel, nghost, domain);
+    const char* eq_from = std::getenv("LBM_EQ_FROM");
+    if (eq_from) {                                          // noiseSwitch: the equilibrium state from DISK, :216-220
+      const int estep = std::getenv("LBM_EQ_STEP") ? std::atoi(std::getenv("LBM_EQ_STEP")) : 0;
+      const std::string r(eq_from);
+      if (!bflbm::LoadSingleMultiFab(r + "/equilibrium_rho", rho_eq) || !bflbm::LoadSingleMultiFab(r + "/equilibrium_phi", phi_eq) ||
+          !bflbm::LoadSingleMultiFab(r + "/equilibrium_rhot", rhot_eq)) return 3;
+      if (!bflbm::LoadSingleMultiFab(bflbm::Concatenate(r + "/f_checkpoint", estep), f0) ||
+          !bflbm::LoadSingleMultiFab(bflbm::Concatenate(r + "/g_checkpoint", estep), g0)) return 3;
+      std::printf("Mass rho_eq = %.17g\n", rho_eq.sum(0));   // :224
+    } else {
+      for (MFIter mfi(hydrovs); mfi.isValid(); ++mfi) {
+        const Box& v = mfi.validbox();
+        for (int z = v.smallEnd(2); z <= v.bigEnd(2); ++z) for (int y = v.smallEnd(1); y <= v.bigEnd(1); ++y) for (int x = v.smallEnd(0); x <= v.bigEnd(0); ++x) {
+          rho_eq[mfi](x, y, z, 0) = hydrovs[mfi](x, y, z, 0);
+          phi_eq[mfi](x, y, z, 0) = hydrovs[mfi](x, y, z, 1);
+          rhot_eq[mfi](x, y, z, 0) = hydrovs[mfi](x, y, z, 5);
+        }
       }
+      bflbm::pull_field(geom, bflbm::F_POPS, f0, &g0);
     }
     bflbm::invalidate_ref_state();                          // the fields changed after the first LBM_* call
     update_com(geom, com_ref[0], rho_eq, true);             // main_run_job.cpp:230-233
     const double off[3] = {2.6, -1.4, 3.3};
     for (int d = 0; d < 3; ++d) com_ref[0][d] -= off[d];
-    MultiFab f0(ba, nvel, nghost, domain), g0(ba, nvel, nghost, domain);
-    bflbm::pull_field(geom, bflbm::F_POPS, f0, &g0);
     LBM_init(geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs, f0, g0, rho_eq, phi_eq, rhot_eq, com_ref);   // :269-270
   }
 #endif
@@ -145,7 +171,33 @@ int main(int argc, char* argv[]) {
     ok = ok && bflbm::WriteSingleLevelPlotfile(bflbm::Concatenate(plot_root + "/gn", nsteps), gnoisevs, ng, geom, (double)nsteps, nsteps);
     ok = ok && bflbm::WriteSingleLevelPlotfile(bflbm::Concatenate(plot_root + "/f_checkpoint", nsteps), fold, {"rho_chk"}, geom, 0., 0);   // 1 name, 19 comps (:406-407)
     ok = ok && bflbm::WriteSingleLevelPlotfile(bflbm::Concatenate(plot_root + "/g_checkpoint", nsteps), gold, {"phi_chk"}, geom, 0., 0);
+    if (kBT == 0.) {
+      // equilibrium state for a later noise run (:423-438; the reference averages its last frames, PrintConvergence,
+      // Debug.H:275-358 -- a converged kBT = 0 run is stationary, here the final frame is written)
+      const char* nm[3] = {"rho", "phi", "rhot"};
+      const int cmp[3] = {0, 1, 5};
+      for (int q = 0; q < 3; ++q) {
+        MultiFab one(ba, 1, nghost, domain);
+        for (MFIter mfi(one); mfi.isValid(); ++mfi) {
+          const Box& v = mfi.validbox();
+          for (int z = v.smallEnd(2); z <= v.bigEnd(2); ++z) for (int y = v.smallEnd(1); y <= v.bigEnd(1); ++y) for (int x = v.smallEnd(0); x <= v.bigEnd(0); ++x)
+            one[mfi](x, y, z, 0) = hydrovs[mfi](x, y, z, cmp[q]);
+        }
+        ok = ok && bflbm::WriteSingleLevelPlotfile(plot_root + "/equilibrium_" + nm[q], one, {std::string(nm[q]) + "_eq"}, geom, (double)nsteps, nsteps);
+      }
+    }
     std::printf("plotfiles %d\n", (int)ok);
+  }
+  if (std::getenv("LBM_EDIT_CHECK") && std::atoi(std::getenv("LBM_EDIT_CHECK")) != 0) {
+    // a driver that edits the populations on the host and asks for the densities of WHAT IT HOLDS (LBM_binary.H:343-354)
+    for (MFIter mfi(fold); mfi.isValid(); ++mfi) {
+      const Box& v = mfi.validbox();
+      for (int c = 0; c < nvel; ++c) for (int z = v.smallEnd(2); z <= v.bigEnd(2); ++z) for (int y = v.smallEnd(1); y <= v.bigEnd(1); ++y) for (int x = v.smallEnd(0); x <= v.bigEnd(0); ++x)
+        fold[mfi](x, y, z, c) *= 1.5;
+    }
+    const double before = hydrovsbar.at(0, 0, nz > 4 ? 4 : 0, 0);
+    LBM_hydrovars_density(geom, fold, gold, hydrovsbar);
+    std::printf("edit_check rho_before %.17g rho_after %.17g\n", before, hydrovsbar.at(0, 0, nz > 4 ? 4 : 0, 0));
   }
   bflbm::shutdown();
   return 0;

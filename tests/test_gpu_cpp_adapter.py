@@ -168,3 +168,64 @@ def test_cpp_structfact_object_writes_the_python_files(pkg, tmp_path):
         for f in ("Header", "Level_0/Cell_H", "Level_0/Cell_D_00000"):
             assert filecmp.cmp(out / name / f, py / name / f, shallow=False), (name, f)
     sf.close(); lbm.close()
+
+
+def _run_env(env, *args, exe=EXE):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = {}
+    for line in r.stdout.splitlines():
+        k, _, v = line.partition(" ")
+        out[k] = v.split()
+    return out
+
+
+OBSERVED = ("total_mass", "rho_mass", "rho(0,0,4)", "ufz(0,0,2)", "fold(1,1,1,3)", "com")
+
+
+def test_cpp_restart_from_disk_equals_uninterrupted_run(tmp_path):
+    """main_run_job.cpp:253-270 in C++: run 7 steps and write the f/g checkpoints, restart a NEW process from those
+    files with LoadSingleMultiFab (AMReX_FileIO.H:18-34) + LBM_init, run 5 more: every printed observable equals the
+    uninterrupted 12-step run (kBT = 0; a noise run restarts its noise index like the reference restarts its RNG)."""
+    n = 12
+    root = str(tmp_path / "chk")
+    os.makedirs(root)
+    first = _run(n, 7, "droplet", 0, 2.5, 2, root)
+    assert first["plotfiles"] == ["1"]
+    resumed = _run_env({"LBM_RESTART_FROM": root, "LBM_RESTART_STEP": 7}, n, 5, "droplet", 0, 2.5, 2)
+    straight = _run(n, 12, "droplet", 0, 2.5, 2)
+    for k in OBSERVED:
+        assert resumed[k] == straight[k], (k, resumed[k], straight[k])
+    assert "Load" in resumed and resumed["Load"][:2] == ["in", "MultiFab"]
+
+
+def test_cpp_noise_switch_flow_from_files(tmp_path):
+    """main_run_job.cpp:216-239: the equilibrium state and the populations of a kBT = 0 run are read back from its
+    plotfiles by the USE_REF_STATE build; the noise run that follows equals the one fed from memory."""
+    exe_ref = EXE + "_ref"
+    n = 12
+    root = str(tmp_path / "eq")
+    os.makedirs(root)
+    _run(n, 0, "droplet", 0, 2.0, 2, root)                                   # writes equilibrium_* and the checkpoints of step 0
+    from_files = _run_env({"LBM_EQ_FROM": root, "LBM_EQ_STEP": 0}, n, 4, "droplet", 1e-5, 2.0, 2, exe=exe_ref)
+    from_memory = _run_env({}, n, 4, "droplet", 1e-5, 2.0, 2, exe=exe_ref)
+    for k in OBSERVED + ("fnoise(1,2,3,4)",):
+        assert from_files[k] == from_memory[k], (k, from_files[k], from_memory[k])
+
+
+def test_operators_evaluate_the_populations_they_are_given(ob):
+    """LBM_hydrovars_density(geom, mf, mg, hydrovsbar) on populations the driver edited on the host (x 1.5):
+    the reference sums what it is handed (LBM_binary.H:315-354); the adapter uploads them first."""
+    o = _run_env({"LBM_EDIT_CHECK": 1}, 10, 3, "stripe", 0, 4.0, 2)
+    before, after = float(o["edit_check"][1]), float(o["edit_check"][3])
+    ref = ob.OracleLattice(10, 10, 10)
+    ref.init_stripe(0.5)
+    for _ in range(3):
+        ref.timestep()
+    assert before == ref.hbar[0, 4, 0, 0]
+    want = 0.0
+    for i in range(19):
+        want += 1.5 * ref.f[i, 4, 0, 0]
+    assert after == want
