@@ -95,8 +95,12 @@ __device__ __forceinline__ double ho_shl(double v) {   // value of lane+1 (trave
   return __hiloint2double(hi, lo);
 }
 
-template <int TY>
-__global__ void __launch_bounds__(64 * TY, 2)
+// PIPE = false: two workgroups per CU at two waves per SIMD (256 registers; the frame producer spills).
+// PIPE = true: ONE workgroup per CU at one wave per SIMD (512 registers per lane, AGPRs included, 160 KB of LDS): the
+// pending plane of BOTH fluids waits in LDS, and the loads of plane q+1 are issued before plane q-1 is collided, so
+// that memory latency runs under the arithmetic inside one wave instead of between waves.
+template <int TY, bool PIPE>
+__global__ void __launch_bounds__(64 * TY, PIPE ? 1 : 2)
 k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParams P, FusedGrid F, HoGrid Hg) {
   using L = HoLayout<TY>;
   constexpr int TX = 64, NT = TX * TY, NW = TY;
@@ -106,6 +110,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   static_assert(TY >= 4 && NPER <= 64 && 8 * TY <= 64, "tile shape");
   __shared__ double rp[4][2][LSZ];                     // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
   __shared__ double gl[Q][NT];                         // g populations of the previous plane
+  __shared__ double fl[PIPE ? Q : 1][PIPE ? NT : 1];   // PIPE: f populations of the previous plane (registers otherwise)
   __shared__ double exch[2][2][2][2][TX];              // [buf][fluid][side][0 edge row's own sum, 1 sum handed over by the row next to it][lane]
   __shared__ double accs[2][2][2][TX];                 // [stage][fluid][side][lane] z pipeline of the edge rows' own sums
   __shared__ double colacc[2][2][2][TY][6];            // [stage][fluid][side][row][kind] z pipeline of the column lanes
@@ -213,26 +218,50 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     }
   };
 
+  // issue the loads of plane q: the own site's 38 populations and, when the ring of that plane comes from frames, its pieces
+  auto pull_plane = [&](int q, double (&f)[Q], double (&g)[Q], double (&hv)[2][4]) {
+    const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
+                                         S + (long long)wrapp(q + 1) * G.plane };
+    unsigned oo[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < 3; ++b2) { oo[a][b2] = yo[a] + xo[b2]; asm volatile("" : "+v"(oo[a][b2])); }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
+      const unsigned o = oo[1 - Vel::cy[i]][1 - Vel::cx[i]];
+      f[i] = ld(b, o);
+      g[i] = ld(b + (long long)Q * G.vol, o);
+    }
+    if (Hg.use_frames && q >= fa && q <= fb && has_rtask) {
+      const double* __restrict__ fp = Hg.fin + (long long)q * Hg.fplane;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned o = fo[j];
+        asm volatile("" : "+v"(o));
+        if (j < 2 || j < nfo) { hv[0][j] = ld(fp, o); hv[1][j] = ld(fp + L::FR, o); }
+        else { hv[0][j] = 0.; hv[1][j] = 0.; }
+      }
+    }
+  };
+  double nf[Q], ng[Q], hvn[2][4];                            // PIPE: the plane in flight
+  if (PIPE) pull_plane(qa - 1, nf, ng, hvn);
+
   int it = 0;
   for (int q = qa - 1; q <= qb; ++q, ++it) {
     const int slot = it & 3;
     const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
                                          S + (long long)wrapp(q + 1) * G.plane };
-    // 1. pull plane q
-    double cf[Q], cg[Q];
-    {
-      unsigned oo[3][3];
+    // 1. plane q: pulled now, or (PIPE) pulled while the previous plane was collided
+    double cf[Q], cg[Q], hv[2][4];
+    if (PIPE) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
+      for (int i = 0; i < Q; ++i) { cf[i] = nf[i]; cg[i] = ng[i]; }
 #pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) { oo[a][b2] = yo[a] + xo[b2]; asm volatile("" : "+v"(oo[a][b2])); }
-#pragma unroll
-      for (int i = 0; i < Q; ++i) {
-        const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
-        const unsigned o = oo[1 - Vel::cy[i]][1 - Vel::cx[i]];
-        cf[i] = ld(b, o);
-        cg[i] = ld(b + (long long)Q * G.vol, o);
-      }
+      for (int j = 0; j < 4; ++j) { hv[0][j] = hvn[0][j]; hv[1][j] = hvn[1][j]; }
+    } else {
+      pull_plane(q, cf, cg, hv);
     }
     const bool ring_from_frames = Hg.use_frames && q >= fa && q <= fb;       // uniform over the workgroup
     double zero = 0.0;
@@ -242,17 +271,6 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       for (int i = 0; i < Q; ++i) r += fs[i];
       return r; };
     if (ring_from_frames) {
-      double hv[2][4];
-      if (has_rtask) {
-        const double* __restrict__ fp = Hg.fin + (long long)wrapp(q) * Hg.fplane;   // q is in [fa, fb]; wrapp only keeps ablation builds in range
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          unsigned o = fo[j];
-          asm volatile("" : "+v"(o));
-          if (j < 2 || j < nfo) { hv[0][j] = ld(fp, o); hv[1][j] = ld(fp + L::FR, o); }
-          else { hv[0][j] = 0.; hv[1][j] = 0.; }
-        }
-      }
       rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg);
       if (has_rtask) {
         double r0 = hv[0][0] + hv[0][1], r1 = hv[1][0] + hv[1][1];
@@ -300,12 +318,27 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       d_moments(pg, mg);
       d_momentum(pg, jg);
     }
+    double mf[Q], jf[3];
+    if (do_collide) {
+      if (PIPE) {
+        double pfl[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) pfl[i] = fl[i][tid];
+        d_moments(pfl, mf);
+        d_momentum(pfl, jf);
+      } else {
+        d_moments(pf, mf);
+        d_momentum(pf, jf);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < Q; ++i) gl[i][tid] = cg[i];
+    if (PIPE) {
+#pragma unroll
+      for (int i = 0; i < Q; ++i) fl[i][tid] = cf[i];
+      if (q + 1 <= qb) pull_plane(q + 1, nf, ng, hvn);       // in flight while plane q-1 is collided
+    }
     if (do_collide) {
-      double mf[Q], jf[3];
-      d_moments(pf, mf);
-      d_momentum(pf, jf);
       const int sl[3] = { (it - 2) & 3, (it - 1) & 3, it & 3 };
       const double r = rp[sl[1]][0][lown], ph = rp[sl[1]][1][lown];
       double nb[Q], grad_rho[3], grad_phi[3];
@@ -394,8 +427,10 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
       finish_fluid(mg, 1);
     }
+    if (!PIPE) {
 #pragma unroll
-    for (int i = 0; i < Q; ++i) pf[i] = cf[i];
+      for (int i = 0; i < Q; ++i) pf[i] = cf[i];
+    }
   }
   // the last complete plane (qb-2) was finished at the last position; combine it across rows
   __syncthreads();
@@ -431,7 +466,8 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
   const int np = pb - pa;
   static const int want_env = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 0; }();
   // two 256-thread workgroups are resident per CU (LDS and registers), so a round is 2 x ncu workgroups
-  const int slots = (g_fused_ncu > 0 ? g_fused_ncu : 256) * (TY == 4 ? 2 : 1);
+  static const bool pipe_slots = [] { const char* e = getenv("BFLBM_HO_PIPE"); return e ? atoi(e) != 0 : true; }();
+  const int slots = (g_fused_ncu > 0 ? g_fused_ncu : 256) * ((TY == 4 && !pipe_slots) ? 2 : 1);
   static const int min_slab_rounds = [] { const char* e = getenv("BFLBM_SLAB_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
   const int maxchunks = std::max(1, np / 4);                     // a chunk shorter than 4 planes has no complete frame
   int nchunks;
@@ -462,7 +498,9 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
   Hg.fplane = (long long)F.ncols * HoLayout<TY>::REC;
   Hg.use_frames = (sig_in.step == steps - 1 && sig_in.same_geometry(sig_out)) ? 1 : 0;
   dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
-  hipLaunchKernelGGL((k_fused_ho<TY>), grid, block, 0, stream, S, D, G, P, F, Hg);
+  static const bool pipe = [] { const char* e = getenv("BFLBM_HO_PIPE"); return e ? atoi(e) != 0 : true; }();
+  if (pipe) hipLaunchKernelGGL((k_fused_ho<TY, true>), grid, block, 0, stream, S, D, G, P, F, Hg);
+  else      hipLaunchKernelGGL((k_fused_ho<TY, false>), grid, block, 0, stream, S, D, G, P, F, Hg);
   return hipGetLastError() != hipSuccess;
 }
 
