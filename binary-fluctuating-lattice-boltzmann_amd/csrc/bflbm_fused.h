@@ -77,7 +77,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   __shared__ double rp[4][2][LSZ];               // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
   __shared__ double gl[Q][TX * TY];              // g populations of the previous plane
   __shared__ float ntab[MODE == 1 ? BFLBM_NORMAL_TABLE_FLOATS : 4];
-  __shared__ double n3l[MODE == 1 ? 3 : 1][MODE == 1 ? TX * TY : 1];   // MODE 1: momentum-mode noise of the site being collided (thread-private column)
+  __shared__ double n3l[3][MODE == 1 ? TX * TY : 1];   // MODE 1: momentum-mode noise of the site being collided (thread-private column)
   if (MODE == 1) d_load_normal_table(ntab, true);
 
   int col, chunk;
