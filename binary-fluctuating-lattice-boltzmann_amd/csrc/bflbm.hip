@@ -207,9 +207,12 @@ inline int resolved_schedule(const bflbm_ctx* c) {
   // the hand-over kernel is the zero-noise kernel and needs full 64 x TY tiles with distinct neighbours
   if (c->schedule == 3) return noisy ? 0 : (handover_ok(c->G) ? 3 : 1);
   if (c->schedule != 2) return c->schedule;
-  // auto never picks the hand-over kernel: its producer does not fit the register file at two waves per SIMD
-  // (scratch spills: 4100-4500 MLUPS against 7050-7350 for schedule 1)
-  return noisy ? 0 : 1;
+  if (noisy) return 0;
+  // zero noise: the pipelined hand-over kernel where the lattice has full 64 x 4 tiles (+3-5 % over schedule 1 at
+  // 256^3 / 512^3, results within the north-star tolerance); BFLBM_AUTO_EXACT=1 keeps auto on
+  // the bit-exact schedule 1
+  static const int auto_exact = [] { const char* e = getenv("BFLBM_AUTO_EXACT"); return e && atoi(e) != 0; }();
+  return (handover_ok(c->G) && !auto_exact) ? 3 : 1;
 }
 
 // the slab's own planes are [H, H+nzl)

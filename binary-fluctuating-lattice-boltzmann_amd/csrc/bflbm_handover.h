@@ -266,7 +266,10 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       for (int i = 0; i < Q; ++i) { cf[i] = nf[i]; cg[i] = ng[i]; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { hv[0][j] = hvn[0][j]; hv[1][j] = hvn[1][j]; }
-      if (HO_EARLY && q + 1 <= qb) pull_plane(q + 1, nf, ng, hvn, HO_SPLIT ? 1 : 0);
+      if (HO_EARLY && q + 1 <= qb) {
+        pull_plane(q + 1, nf, ng, hvn, HO_SPLIT ? 1 : 0);
+        if (HO_SPLIT && !(q - 1 >= qa && q - 1 < qb)) pull_plane(q + 1, nf, ng, hvn, 2);
+      }
     } else {
       pull_plane(q, cf, cg, hv);
     }
@@ -343,7 +346,11 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     if (PIPE) {
 #pragma unroll
       for (int i = 0; i < Q; ++i) fl[i][tid] = cf[i];
-      if (!HO_EARLY && q + 1 <= qb) pull_plane(q + 1, nf, ng, hvn, HO_SPLIT ? 1 : 0);   // in flight while plane q-1 is collided
+      // in flight while plane q-1 is collided; without a collision at this position both halves go now
+      if (!HO_EARLY && q + 1 <= qb) {
+        pull_plane(q + 1, nf, ng, hvn, HO_SPLIT ? 1 : 0);
+        if (HO_SPLIT && !do_collide) pull_plane(q + 1, nf, ng, hvn, 2);     // the first two positions of a chunk collide nothing: both halves now
+      }
     }
     if (do_collide) {
       const int sl[3] = { (it - 2) & 3, (it - 1) & 3, it & 3 };

@@ -94,10 +94,11 @@ int bflbm_set_stream(bflbm_ctx* c, void* hip_stream, int external);
 /* Kernel schedule: 0 = two-pass (density pass + collide pass), 1 = fused plane-marching kernel with the
  * tile-ring densities pulled, 3 = fused plane-marching kernel with the tile-ring densities handed over from
  * the previous step (csrc/bflbm_handover.h; zero noise, lattices of full 64 x 4 tiles -- otherwise it resolves
- * to 1 or 0; opt-in: slower than 1 today), 2 = auto (default): 1 at zero noise, 0 when thermal noise is on.
+ * to 1 or 0), 2 = auto (default): at zero noise 3 where it applies, else 1; 0 when thermal noise is on.
  * Schedules 0 and 1 give identical doubles (= the CPU reference's operation order).  Schedule 3 sums the 19
  * populations of a tile-ring density in another fixed order: deterministic, within 1 ulp of rho,phi per step
- * at the tile-edge sites' neighbours, inside the 1e-12 bar on densities/velocities, not bit-identical. */
+ * at the tile-edge sites' neighbours, inside the 1e-12 bar on densities/velocities, not bit-identical.
+ * BFLBM_AUTO_EXACT=1 in the environment makes auto never pick 3. */
 int bflbm_set_schedule(bflbm_ctx* c, int schedule);
 
 /* LBM_init_mixture (LBM_binary.H:598-629), LBM_init_stripe(frac) (:664-695),

@@ -98,12 +98,12 @@ def test_config4_pair_of_1024x1024x64_slabs(pkg):
     """configs[4]'s slab shape: two 1024x1024x64 slabs against the single 1024x1024x128 context (82 GB each way),
     droplet init (analytic, evaluated per slab; a homogeneous mixture would exercise no indexing), 6 steps."""
     nx, ny, nz, steps = 1024, 1024, 128, 6
-    a = pkg.BinaryLBM(nx, ny, nz)
+    a = pkg.BinaryLBM(nx, ny, nz, schedule="fused")
     a.LBM_init_droplet(0.05)
     a.LBM_timestep(steps)
     ha = a.LBM_hydrovars_density()
     a.close()
-    r = pkg.RingLBM(nx, ny, nz, nslabs=2, devices=(0,))
+    r = pkg.RingLBM(nx, ny, nz, nslabs=2, devices=(0,), schedule="fused")
     r.LBM_init_droplet(0.05)
     r.LBM_timestep(steps)
     hr = r.LBM_hydrovars_density()
@@ -133,3 +133,21 @@ def test_handover_schedule_tolerance_contract(pkg, shape, init):
     _tolerances(hh, he)
     (fh2, gh2), _ = run("handover", 50)
     assert np.array_equal(fh, fh2) and np.array_equal(gh, gh2)
+
+
+def test_auto_schedule_at_256_cubed_is_within_tolerance_of_the_exact_one(pkg):
+    """configs[1] with the default (auto) schedule = the pipelined hand-over kernel: 30 steps of the 256^3 droplet agree
+    with the bit-exact fused schedule at the north-star tolerances; a 256^3 box in 3 slabs (hand-over frames inside every
+    slab's interior sweep, pulled rings at the slab faces) does too."""
+    n, steps = 256, 30
+    res = {}
+    for name, make in (("exact", lambda: pkg.BinaryLBM(n, n, n, schedule="fused")), ("auto", lambda: pkg.BinaryLBM(n, n, n)),
+                       ("auto_ring", lambda: pkg.RingLBM(n, n, n, nslabs=3, devices=(0,)))):
+        l = make()
+        l.LBM_init_droplet(0.2)
+        l.LBM_timestep(steps)
+        res[name] = l.LBM_hydrovars()
+        l.close()
+    assert not np.array_equal(res["exact"], res["auto"])        # auto really is the other kernel
+    _tolerances(res["auto"], res["exact"])
+    _tolerances(res["auto_ring"], res["exact"])

@@ -49,7 +49,7 @@ def test_256_cubed_stripe_is_translation_invariant(pkg):
     """Flat interface: the state depends on z only, so after any number of steps every (x,y) column
     must hold bitwise the same doubles -- any mis-indexed tile, wrap or halo breaks this."""
     n = 256
-    lbm = pkg.BinaryLBM(n, n, n)
+    lbm = pkg.BinaryLBM(n, n, n, schedule="fused")     # bitwise statement: the exact schedule (auto = hand-over sums tile-edge rings in another order)
     lbm.LBM_init_stripe(0.5)
     lbm.LBM_timestep(25)
     hb = lbm.LBM_hydrovars_density()
@@ -152,7 +152,7 @@ def test_config5_slab_shape_1024x1024(pkg):
         res[schedule] = lbm.LBM_hydrovars_density()
         lbm.close()
     assert np.array_equal(res["two_pass"], res["fused"])
-    ring = pkg.RingLBM(nx, ny, nz, nslabs=2, params=pkg.default_params(alpha0=2.0))
+    ring = pkg.RingLBM(nx, ny, nz, nslabs=2, params=pkg.default_params(alpha0=2.0), schedule="fused")
     ring.LBM_init_droplet(0.01)
     ring.LBM_timestep(4)
     assert np.array_equal(ring.LBM_hydrovars_density(), res["fused"])

@@ -193,12 +193,12 @@ def test_native_ring(pkg, ob, nslabs, n, schedule):
 def test_native_ring_256_matches_single_context(pkg):
     """Overlap hazards show up at size: 4 slabs of 256x256x64 vs the single 256^3 context, 12 steps."""
     n = 256
-    a = pkg.BinaryLBM(n, n, n)
+    a = pkg.BinaryLBM(n, n, n, schedule="fused")
     a.LBM_init_droplet(0.2)
     a.LBM_timestep(12)
     ha = a.LBM_hydrovars_density()
     a.close()
-    r = pkg.RingLBM(n, n, n, nslabs=4, devices=(0,))
+    r = pkg.RingLBM(n, n, n, nslabs=4, devices=(0,), schedule="fused")
     r.LBM_init_droplet(0.2)
     r.LBM_timestep(12)
     hr = r.LBM_hydrovars_density()
