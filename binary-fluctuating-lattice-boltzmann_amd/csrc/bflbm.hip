@@ -188,7 +188,7 @@ int launch_handover(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
   if (ensure_frames(c)) return 1;
   const int kind = pair_len > 0 ? 1 : 0;
   return handover_launch(c->S[c->cur], c->S[1 - c->cur], c->frames[c->cur], c->frames[1 - c->cur], c->G, c->dp, pa, pb,
-                         c->steps, c->fsig[c->cur][kind], c->fsig[1 - c->cur][kind], c->stream, pair_len)
+                         c->steps, c->fsig[c->cur][kind], c->fsig[1 - c->cur][kind], c->stream, pair_len, c->dp.noise_on ? 1 : 0)
              ? fail("hand-over launch failed: %s", hipGetErrorString(hipGetLastError())) : 0;
 }
 
@@ -204,10 +204,12 @@ int launch_fused(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
 inline int resolved_schedule(const bflbm_ctx* c) {
   if (ref_active(c)) return 0;                   // needs the densities and their centre of mass first
   const bool noisy = c->dp.noise_on || c->inject;
-  // the hand-over kernel is the zero-noise kernel and needs full 64 x TY tiles with distinct neighbours
-  if (c->schedule == 3) return noisy ? 0 : (handover_ok(c->G) ? 3 : 1);
+  // the hand-over kernel needs full 64 x TY tiles with distinct neighbours; it generates thermal noise itself
+  // (pipelined form) but takes no injected noise
+  if (c->schedule == 3) return c->inject ? 0 : (handover_ok(c->G) ? 3 : (noisy ? 0 : 1));
   if (c->schedule != 2) return c->schedule;
-  if (noisy) return 0;
+  static const int auto_noise_fused = [] { const char* e = getenv("BFLBM_AUTO_NOISE_HANDOVER"); return e ? atoi(e) != 0 : true; }();
+  if (noisy) return (!c->inject && auto_noise_fused && handover_ok(c->G)) ? 3 : 0;
   // zero noise: the pipelined hand-over kernel where the lattice has full 64 x 4 tiles (+3-5 % over schedule 1 at
   // 256^3 / 512^3, results within the north-star tolerance); BFLBM_AUTO_EXACT=1 keeps auto on
   // the bit-exact schedule 1

@@ -105,9 +105,10 @@ __device__ __forceinline__ double ho_shl(double v) {   // value of lane+1 (trave
 // PIPE = true: ONE workgroup per CU at one wave per SIMD (512 registers per lane, AGPRs included, 160 KB of LDS): the
 // pending plane of BOTH fluids waits in LDS, and the loads of plane q+1 are issued before plane q-1 is collided, so
 // that memory latency runs under the arithmetic inside one wave instead of between waves.
-template <int TY, bool PIPE>
+// MODE 0: zero noise; MODE 1: generated thermal noise (csrc/bflbm_rng.h), drawn where it is added.
+template <int TY, bool PIPE, int MODE>
 __global__ void __launch_bounds__(64 * TY, PIPE ? 1 : 2)
-k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParams P, FusedGrid F, HoGrid Hg) {
+k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParams P, FusedGrid F, HoGrid Hg, uint32_t noise_index) {
   using L = HoLayout<TY>;
   constexpr int TX = 64, NT = TX * TY, NW = TY;
   constexpr int LW = TX + 2, LSZ = (TX + 2) * (TY + 2);
@@ -122,8 +123,11 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   __shared__ double colacc[2][2][2][TY][6];            // [stage][fluid][side][row][kind] z pipeline of the column lanes
   __shared__ double colfin[2][2][2][TY][6];            // [buf][fluid][side][row][kind] finished column sums
 
+  __shared__ float ntab[MODE == 1 ? BFLBM_NORMAL_TABLE_FLOATS : 4];
+
   int col, chunk;
-  if (!fused_map(F, (int)blockIdx.x, col, chunk)) return;
+  if (!fused_map(F, (int)blockIdx.x, col, chunk)) return;   // whole workgroup leaves together
+  if (MODE == 1) d_load_normal_table(ntab, true);
   const int tix = col % F.ntx, tiy = col / F.ntx;
   const int x0 = tix * TX, y0 = tiy * TY;
   const int tid = threadIdx.x;
@@ -363,7 +367,14 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       for (int i = 0; i < Q; ++i) nb[i] = rp[sl[1 + Vel::cz[i]]][1][lown + Vel::cy[i] * LW + Vel::cx[i]];
       d_gradient(P, nb, grad_phi);
       const int pcw = wrapp(pc);
-      const double fn3[3] = {0., 0., 0.}, gn3[3] = {0., 0., 0.};
+      double fn3[3] = {0., 0., 0.}, gn3[3] = {0., 0., 0.};
+      NoiseAmp NA; bflbm_rng_state rst;
+      if (MODE == 1) {
+        d_noise_amp(P, r, ph, r + ph, NA);
+        d_noise_head(P, NA, global_site(G, x, y, pcw), noise_index, ntab, rst, fn3);
+#pragma unroll
+        for (int k3 = 0; k3 < 3; ++k3) gn3[k3] = -fn3[k3];
+      }
       double* __restrict__ Dp = D + (long long)pcw * G.plane;
       unsigned o = yo[1] + xo[1];
       asm volatile("" : "+v"(o));
@@ -436,10 +447,12 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
           }
         }
       };
-      d_relax<false>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, zn, R.cs4);
+      if (MODE == 1) d_relax_generated(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn3, NA.sr, ntab, rst, R.cs4);
+      else           d_relax<false>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, zn, R.cs4);
       finish_fluid(mf, 0);
       if (PIPE && HO_SPLIT && q + 1 <= qb) pull_plane(q + 1, nf, ng, hvn, 2);   // the g half of the next plane: spreads the requests over the march position
-      d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
+      if (MODE == 1) d_relax_generated(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn3, NA.sp, ntab, rst, R.cs4);
+      else           d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
       finish_fluid(mg, 1);
     }
     if (!PIPE) {
@@ -472,7 +485,7 @@ struct HoSig { int pa = -1, pb = -1, lz = -1, nchunks = -1, cstride = -1; long l
 // fin/fout: frame buffers of the state read / written.  sig_in: what wrote fin (step == steps-1 required);
 // sig_out receives this launch.  returns non-zero on launch failure
 static inline int handover_launch(const double* S, double* D, const double* fin, double* fout, const Geo& G, const DevParams& P,
-                                  int pa, int pb, long long steps, const HoSig& sig_in, HoSig& sig_out, hipStream_t stream, int pair_len = 0) {
+                                  int pa, int pb, long long steps, const HoSig& sig_in, HoSig& sig_out, hipStream_t stream, int pair_len = 0, int mode = 0) {
   constexpr int TX = 64, TY = BFLBM_HO_TY;
   FusedGrid F;
   F.ntx = G.nx / TX; F.nty = G.ny / TY;
@@ -482,7 +495,7 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
   static const int want_env = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 0; }();
   // two 256-thread workgroups are resident per CU (LDS and registers), so a round is 2 x ncu workgroups
   static const bool pipe_slots = [] { const char* e = getenv("BFLBM_HO_PIPE"); return e ? atoi(e) != 0 : true; }();
-  const int slots = (g_fused_ncu > 0 ? g_fused_ncu : 256) * ((TY == 4 && !pipe_slots) ? 2 : 1);
+  const int slots = (g_fused_ncu > 0 ? g_fused_ncu : 256) * ((TY == 4 && !pipe_slots && mode == 0) ? 2 : 1);
   static const int min_slab_rounds = [] { const char* e = getenv("BFLBM_SLAB_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
   const int maxchunks = std::max(1, np / 4);                     // a chunk shorter than 4 planes has no complete frame
   int nchunks;
@@ -514,8 +527,10 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
   Hg.use_frames = (sig_in.step == steps - 1 && sig_in.same_geometry(sig_out)) ? 1 : 0;
   dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
   static const bool pipe = [] { const char* e = getenv("BFLBM_HO_PIPE"); return e ? atoi(e) != 0 : true; }();
-  if (pipe) hipLaunchKernelGGL((k_fused_ho<TY, true>), grid, block, 0, stream, S, D, G, P, F, Hg);
-  else      hipLaunchKernelGGL((k_fused_ho<TY, false>), grid, block, 0, stream, S, D, G, P, F, Hg);
+  const uint32_t nidx = (uint32_t)steps;
+  if (mode == 1)  hipLaunchKernelGGL((k_fused_ho<TY, true, 1>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);   // noise only in the pipelined form
+  else if (pipe)  hipLaunchKernelGGL((k_fused_ho<TY, true, 0>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
+  else            hipLaunchKernelGGL((k_fused_ho<TY, false, 0>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
   return hipGetLastError() != hipSuccess;
 }
 

@@ -151,3 +151,23 @@ def test_auto_schedule_at_256_cubed_is_within_tolerance_of_the_exact_one(pkg):
     assert not np.array_equal(res["exact"], res["auto"])        # auto really is the other kernel
     _tolerances(res["auto"], res["exact"])
     _tolerances(res["auto_ring"], res["exact"])
+
+
+@pytest.mark.parametrize("shape", [(128, 16, 12), (256, 32, 40)])
+def test_thermal_noise_in_the_pipelined_kernel(pkg, shape):
+    """With kBT > 0 auto runs the pipelined hand-over kernel with the generator inside (one pass per step).  Same
+    stream and amplitudes as the two-pass schedule: the first step is bit-identical, later steps differ only through the
+    summation order of the tile-ring densities (rounding level after 30 steps)."""
+    par = pkg.default_params(kBT=1e-5, alpha0=1.0)
+    out = {}
+    for steps in (1, 30):
+        for sched in ("two_pass", "handover"):
+            with pkg.BinaryLBM(*shape, params=par, schedule=sched) as l:
+                l.LBM_init_droplet(0.25)
+                l.LBM_timestep(steps)
+                out[sched, steps] = l.populations()
+    for k in (0, 1):
+        assert np.array_equal(out["two_pass", 1][k], out["handover", 1][k])
+        assert np.abs(out["two_pass", 30][k] - out["handover", 30][k]).max() < 1e-13
+    f = out["handover", 30][0]
+    assert np.abs(f - f.mean(axis=(1, 2, 3), keepdims=True)).max() > 1e-6          # the noise is there
