@@ -97,9 +97,13 @@ template <typename TabPtr>
 BFLBM_HD float bflbm_normal_from_bits(uint32_t u, TabPtr tab) {
   const uint32_t sign = u & 0x80000000u, v = u & 0x7FFFFFFFu;
   const uint32_t lz = bflbm_clz32(v);                   // 1..32: octave + 1
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t top = v << (lz & 31u);                 // v == 0: lz = 32 shifts by 0 and leaves 0 (what the hardware does anyway)
+#else
   const uint32_t top = (lz >= 32u) ? 0u : (v << lz);    // leading one at bit 31
+#endif
   const uint32_t r = top << 1;                          // the bits after it, left-aligned
-  const uint32_t oct = (lz >= 32u) ? 31u : lz - 1u;
+  const uint32_t oct = (lz - 1u < 31u) ? lz - 1u : 31u; // min(lz - 1, 31)
   const uint32_t cell = oct * 4u + (r >> 30);
   const float W = (float)((r >> 6) & 0xFFFFFFu);        // 24 bits: exact
   const float c0 = tab[cell * 4u + 0u], c1 = tab[cell * 4u + 1u], c2 = tab[cell * 4u + 2u], c3 = tab[cell * 4u + 3u];

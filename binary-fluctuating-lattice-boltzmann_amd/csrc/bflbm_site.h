@@ -443,8 +443,11 @@ __device__ __forceinline__ void d_relax_generated(const DevParams& P, double (&m
   float nrm[Q - 4];
 #pragma unroll
   for (int k = 4; k < Q; ++k) nrm[k - 4] = bflbm_normal_from_bits(bflbm_rng_next(st), tab);
+  double amp[6];                                 // the six distinct amplitudes of this fluid (same products as d_noise_mode)
+#pragma unroll
+  for (int g = 0; g < 6; ++g) amp[g] = P.samp[g] * s;
   d_relax_with<true>(P, m, rho_k, v_b, u, a, inv_tau_bar,
-                     [&](int k) { return k == 0 ? 0. : (k < 4 ? n3[k - 1] : (P.samp[d_noise_group(k)] * s) * (double)nrm[k - 4]); }, ycs4);
+                     [&](int k) { return k == 0 ? 0. : (k < 4 ? n3[k - 1] : amp[d_noise_group(k)] * (double)nrm[k - 4]); }, ycs4);
 }
 
 __device__ __forceinline__ void d_barycentric(double rho, double phi, const SiteHydro& H, double (&v_b)[3], const SiteRecip& R) {
