@@ -151,6 +151,7 @@ def main():
             def barrier():
                 eng.sync()
 
+        eng_schedule = eng.resolved_schedule() if hasattr(eng, "resolved_schedule") else a.schedule    # what auto resolves to
         getattr(lat, "LBM_init_" + a.init)(*([0.5] if a.init == "stripe" else [0.2] if a.init == "droplet" else []))
         lat.LBM_timestep(a.warmup)
         barrier()
@@ -193,7 +194,7 @@ def main():
         per_gpu_sites = sites / world
         kern_ms = dev_ms / a.steps
         achieved = per_gpu_sites * BYTES_PER_LUP / (kern_ms * 1e-3) / 1e9
-        schedule = a.schedule if a.schedule != "auto" else ("two_pass" if a.noise else "fused")
+        schedule = eng_schedule
         workload = f"{nx}x{ny}x{nz} periodic, {a.init} init, " + ("kBT=1e-5 alpha0=0" if a.noise else "zero noise")
         return {
             "value": round(sites * a.steps / wall / 1e6, 1), "ms_per_step": round(wall / a.steps * 1e3, 4),

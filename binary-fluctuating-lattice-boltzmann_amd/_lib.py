@@ -54,6 +54,7 @@ SIGNATURES = {
     "bflbm_get_params": (ctypes.c_int, [_vp, _P(Params)]),
     "bflbm_set_stream": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
     "bflbm_set_schedule": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "bflbm_resolved_schedule": (ctypes.c_int, [_vp, _P(ctypes.c_int)]),
     "bflbm_init_mixture": (ctypes.c_int, [_vp]),
     "bflbm_init_stripe": (ctypes.c_int, [_vp, ctypes.c_double]),
     "bflbm_init_droplet": (ctypes.c_int, [_vp, ctypes.c_double]),

@@ -452,6 +452,12 @@ int bflbm_set_stream(bflbm_ctx* c, void* s, int external) {
   return 0;
 }
 
+int bflbm_resolved_schedule(const bflbm_ctx* c, int* schedule) {
+  if (!c || !schedule) return fail("null argument");
+  *schedule = resolved_schedule(c);
+  return 0;
+}
+
 int bflbm_set_schedule(bflbm_ctx* c, int schedule) {
   if (!c) return fail("null context");
   if (schedule < 0 || schedule > 3) return fail("unknown schedule %d", schedule);

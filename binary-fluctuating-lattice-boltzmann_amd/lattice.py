@@ -156,6 +156,12 @@ class BinaryLBM(_DropletMixin):
 
     # -- shapes ----------------------------------------------------------------------------
     @property
+    def resolved_schedule(self):
+        """Name of the schedule the next step runs (auto resolved for the current parameters and lattice)."""
+        v = ctypes.c_int()
+        check(self.lib.bflbm_resolved_schedule(self._h, ctypes.byref(v)))
+        return {0: "two_pass", 1: "fused", 3: "handover"}[v.value]
+
     def slab_shape(self):
         return (self.nzl, self.n[1], self.n[0])
 

@@ -100,6 +100,8 @@ int bflbm_set_stream(bflbm_ctx* c, void* hip_stream, int external);
  * at the tile-edge sites' neighbours, inside the 1e-12 bar on densities/velocities, not bit-identical.
  * BFLBM_AUTO_EXACT=1 in the environment makes auto never pick 3. */
 int bflbm_set_schedule(bflbm_ctx* c, int schedule);
+/* The schedule (0, 1 or 3) the next step of this context will run with its current parameters and lattice. */
+int bflbm_resolved_schedule(const bflbm_ctx* c, int* schedule);
 
 /* LBM_init_mixture (LBM_binary.H:598-629), LBM_init_stripe(frac) (:664-695),
  * LBM_init_droplet(r) (:699-742).  Resets the step counter to 0. */
