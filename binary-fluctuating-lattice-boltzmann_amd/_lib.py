@@ -107,6 +107,12 @@ SIGNATURES = {
     "bflbm_sf_accumulate": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "bflbm_sf_nsamples": (ctypes.c_int, [_vp, _P(ctypes.c_longlong)]),
     "bflbm_sf_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "bflbm_ring_sf_create": (ctypes.c_int, [_vp, ctypes.c_int, _P(ctypes.c_int), _P(ctypes.c_int), _dp, _P(_vp)]),
+    "bflbm_ring_sf_destroy": (ctypes.c_int, [_vp]),
+    "bflbm_ring_sf_reset": (ctypes.c_int, [_vp]),
+    "bflbm_ring_sf_accumulate": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "bflbm_ring_sf_nsamples": (ctypes.c_int, [_vp, _P(ctypes.c_longlong)]),
+    "bflbm_ring_sf_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     "bflbm_timer_start": (ctypes.c_int, [_vp]),
     "bflbm_timer_stop": (ctypes.c_int, [_vp, _P(ctypes.c_float)]),
     "bflbm_rng_site_normals": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _dp]),

@@ -1131,4 +1131,5 @@ int bflbm_ring_sync(bflbm_ring* r) {
 }  // extern "C"
 
 #include "bflbm_sf.h"
+#include "bflbm_sf_ring.h"
 #include "bflbm_droplet.h"

@@ -155,13 +155,13 @@ class BinaryLBM(_DropletMixin):
         check(self.lib.bflbm_set_schedule(self._h, int(code)))
 
     # -- shapes ----------------------------------------------------------------------------
-    @property
     def resolved_schedule(self):
         """Name of the schedule the next step runs (auto resolved for the current parameters and lattice)."""
         v = ctypes.c_int()
         check(self.lib.bflbm_resolved_schedule(self._h, ctypes.byref(v)))
         return {0: "two_pass", 1: "fused", 3: "handover"}[v.value]
 
+    @property
     def slab_shape(self):
         return (self.nzl, self.n[1], self.n[0])
 
@@ -372,6 +372,8 @@ class RingLBM(_DropletMixin):
 
     def close(self):
         if getattr(self, "_h", None):
+            for d in list(getattr(self, "_dependents", [])):      # ring-level accumulators (structure factors)
+                d.close()
             for s in self.slabs:
                 for d in list(getattr(s, "_dependents", [])):
                     d.close()

@@ -73,8 +73,9 @@ class StructFact:
 
 
 class DeviceStructFact(StructFact):
-    """The accumulator on the device: no field leaves the GPU until the mean is written.
-    `lbm` is a single-context BinaryLBM; frames are taken from its resident state."""
+    """The accumulator on the device(s): no field leaves the GPU until the mean is written.
+    `lbm` is a single-context BinaryLBM or a RingLBM (slab-decomposed lattice: distributed slab FFT,
+    csrc/bflbm_sf_ring.h); frames are taken from its resident state."""
 
     def __init__(self, lbm, var_names, pair_a=PAIR_A, pair_b=PAIR_B, var_scaling=None, lb_hydrovars=False):
         import ctypes
@@ -87,7 +88,8 @@ class DeviceStructFact(StructFact):
         b = (ctypes.c_int * n)(*[p[1] for p in self.pairs])
         sc = (ctypes.c_double * n)(*[float(v) for v in self.scale])
         h = ctypes.c_void_p()
-        _lib.check(lbm.lib.bflbm_sf_create(lbm._h, n, a, b, sc, ctypes.byref(h)))
+        self._pre = "bflbm_ring_sf_" if type(lbm).__name__ == "RingLBM" else "bflbm_sf_"
+        _lib.check(getattr(lbm.lib, self._pre + "create")(lbm._h, n, a, b, sc, ctypes.byref(h)))
         self._h = h
         if not hasattr(lbm, "_dependents"):
             lbm._dependents = []
@@ -95,7 +97,7 @@ class DeviceStructFact(StructFact):
 
     def close(self):
         if getattr(self, "_h", None):
-            self._libh.bflbm_sf_destroy(self._h)
+            getattr(self._libh, self._pre + "destroy")(self._h)
             self._h = None
             deps = getattr(self.lbm, "_dependents", [])
             if self in deps:
@@ -109,18 +111,18 @@ class DeviceStructFact(StructFact):
 
     def reset(self):
         if getattr(self, "_h", None):
-            self._check(self._libh.bflbm_sf_reset(self._h))
+            self._check(getattr(self._libh, self._pre + "reset")(self._h))
         self.nsamples = 0
 
     def fort_structure(self, fields=None, reset=0):
         """FortStructure on the resident state (`fields` is ignored: nothing is downloaded)."""
-        self._check(self._libh.bflbm_sf_accumulate(self._h, int(self.lb), int(bool(reset))))
+        self._check(getattr(self._libh, self._pre + "accumulate")(self._h, int(self.lb), int(bool(reset))))
         self.nsamples = 1 if reset else self.nsamples + 1
 
     def _get(self, what, zero_avg):
         nx, ny, nz = self.lbm.n
         out = np.empty((len(self.pairs), nz, ny, nx))
-        self._check(self._libh.bflbm_sf_get(self._h, what, int(bool(zero_avg)), out.ctypes.data_as(self._ct.c_void_p)))
+        self._check(getattr(self._libh, self._pre + "get")(self._h, what, int(bool(zero_avg)), out.ctypes.data_as(self._ct.c_void_p)))
         return out
 
     def mean(self, zero_avg=1):

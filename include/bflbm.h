@@ -236,6 +236,18 @@ int bflbm_sf_accumulate(bflbm_sf* s, int lb_hydrovars, int reset);
 int bflbm_sf_nsamples(const bflbm_sf* s, long long* n);
 int bflbm_sf_get(bflbm_sf* s, int what, int zero_avg, double* dst);
 
+/* The same accumulator for a lattice decomposed into the z-slabs of a bflbm_ring (any number of slabs, on one or
+ * several GPUs): 2-D transforms of every slab's own planes, a transpose over the slabs (strided peer copies), z
+ * transforms of row blocks, pair products per slab; bflbm_ring_sf_get assembles and expands the mean on the host.
+ * Same arguments, normalisation and output layout as bflbm_sf_*; a ring of one slab delegates to it. */
+typedef struct bflbm_ring_sf bflbm_ring_sf;
+int bflbm_ring_sf_create(bflbm_ring* r, int npairs, const int* var_a, const int* var_b, const double* scale, bflbm_ring_sf** out);
+int bflbm_ring_sf_destroy(bflbm_ring_sf* s);
+int bflbm_ring_sf_reset(bflbm_ring_sf* s);
+int bflbm_ring_sf_accumulate(bflbm_ring_sf* s, int lb_hydrovars, int reset);
+int bflbm_ring_sf_nsamples(const bflbm_ring_sf* s, long long* n);
+int bflbm_ring_sf_get(bflbm_ring_sf* s, int what, int zero_avg, double* dst);
+
 /* ---- Droplet observables reduced on the device (Droplet_Fluctuation.ipynb / Surface_Tension.ipynb
  * cell 3; the reference's C++ twins getCenterOfMass / fittingDropletCovariance / fittingDropletParams,
  * LBM_hydrovs.H:62-335, are off by default, main_run_job.cpp:111).

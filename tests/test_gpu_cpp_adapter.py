@@ -229,3 +229,22 @@ def test_operators_evaluate_the_populations_they_are_given(ob):
     for i in range(19):
         want += 1.5 * ref.f[i, 4, 0, 0]
     assert after == want
+
+
+def test_cpp_structfact_on_a_decomposed_lattice(pkg, tmp_path):
+    """The same FHDeX call shapes with the adapter's lattice split into 3 z-slabs (BFLBM_NSLABS=3): bflbm::StructFact sits
+    on bflbm_ring_sf_* and writes the spectra of the unsplit run (1e-11 of each pair's largest value)."""
+    pf = pkg.plotfile
+    n, steps, kbt = 12, 40, 1e-5
+    res = {}
+    for tag, env in (("one", {}), ("three", {"BFLBM_NSLABS": "3"})):
+        out = tmp_path / tag; out.mkdir()
+        r = subprocess.run([EXE, str(n), str(steps), "mixture", str(kbt), "0", "2", str(out)], capture_output=True, text=True,
+                           timeout=300, env=dict(os.environ, LBM_SF_WINDOW="30", LBM_SF_STEP="10", **env))
+        assert r.returncode == 0, r.stderr
+        assert "sf_samples 4" in r.stdout
+        res[tag] = [pf.read_plotfile(str(out / (name % steps)))[0] for name in ("plt_SF_mag%09d", "plt_SF_real_imag%09d")]
+    for a, b in zip(res["one"], res["three"]):
+        assert a.shape == b.shape
+        scale = np.abs(a).reshape(a.shape[0], -1).max(axis=1)[:, None, None, None] + 1e-300
+        assert np.all(np.abs(a - b) <= 1e-11 * scale)
