@@ -308,7 +308,10 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
                                uint32_t noise_index, int mode, hipStream_t stream, int pair_len = 0) {
   // pair_len > 0: ONE launch over the two disjoint plane ranges [pa, pa+pair_len) and [pb-pair_len, pb)
   // (the boundary plane pairs of a slab), one chunk each.
-  constexpr int TX = BFLBM_FUSED_TX, TY = BFLBM_FUSED_TY;
+  // Tile shape: 64 x 8 sites; lattices narrower than 64 in x get the same 512 sites as 32 x 16, 16 x 32 or 8 x 64
+  // (zero noise only; e.g. the reference's 8 x 256 x 64 flat-interface box would use 8 of 64 lanes of a 64-wide tile)
+  const int TX = (mode != 0 || G.nx > 32) ? BFLBM_FUSED_TX : (G.nx > 16 ? 32 : (G.nx > 8 ? 16 : 8));
+  const int TY = (BFLBM_FUSED_TX * BFLBM_FUSED_TY) / TX;
   FusedGrid F;
   F.ntx = (G.nx + TX - 1) / TX;
   F.nty = (G.ny + TY - 1) / TY;
@@ -353,9 +356,13 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   F.per_xcd = (F.total + 7) / 8;
   { static const int sx_env = [] { const char* e = getenv("BFLBM_MAP_SX"); return e ? atoi(e) : 0; }(); F.sx = sx_env > 0 ? sx_env : std::min(F.ntx, 4); }   // strips of 4 tiles: +2 % at 512^3 (ntx = 8), identical at 256^3
   dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
-  if (mode == 2)      hipLaunchKernelGGL((k_fused<TX, TY, 2>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
-  else if (mode == 1) hipLaunchKernelGGL((k_fused<TX, TY, 1>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
-  else                hipLaunchKernelGGL((k_fused<TX, TY, 0>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
+  constexpr int TX0 = BFLBM_FUSED_TX, TY0 = BFLBM_FUSED_TY;
+  if (mode == 2)      hipLaunchKernelGGL((k_fused<TX0, TY0, 2>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
+  else if (mode == 1) hipLaunchKernelGGL((k_fused<TX0, TY0, 1>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
+  else if (TX == 32)  hipLaunchKernelGGL((k_fused<32, (TX0 * TY0) / 32, 0>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
+  else if (TX == 16)  hipLaunchKernelGGL((k_fused<16, (TX0 * TY0) / 16, 0>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
+  else if (TX == 8)   hipLaunchKernelGGL((k_fused<8, (TX0 * TY0) / 8, 0>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
+  else                hipLaunchKernelGGL((k_fused<TX0, TY0, 0>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
   return hipGetLastError() != hipSuccess;
 }
 
