@@ -158,7 +158,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
         const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
-        const unsigned o = oo[1 - Vel::cy[i]][1 - Vel::cx[i]];
+        const unsigned o = oo[1 - Vel::cy[i]][1 + BFLBM_PX(Vel::cx[i])];
         cf[i] = ld(b, o);
         cg[i] = ld(b + (long long)Q * G.vol, o);
       }
@@ -178,7 +178,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
         const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)hfl * Q * G.vol + (long long)i * G.vol;
-        hv[i] = ld(b, ho[1 - Vel::cy[i]][1 - Vel::cx[i]]);
+        hv[i] = ld(b, ho[1 - Vel::cy[i]][1 + BFLBM_PX(Vel::cx[i])]);
       }
     } else {
 #pragma unroll
@@ -244,6 +244,8 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
       double* __restrict__ Dp = D + (long long)pc * G.plane;
       unsigned o = yo[1] + xo[1];
       asm volatile("" : "+v"(o));
+      unsigned os3[3] = { yo[1] + xo[0], o, yo[1] + xo[2] };       // store slots of populations with c_x = -1, 0, +1 (BFLBM_XSHIFT)
+      if (BFLBM_XSHIFT) { asm volatile("" : "+v"(os3[0])); asm volatile("" : "+v"(os3[2])); }
       {
         SiteHydro Hy;
         SiteRecip R;
@@ -267,7 +269,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
           double out[Q];
           d_populations(mf, out);
 #pragma unroll
-          for (int i = 0; i < Q; ++i) st(Dp + (long long)i * G.vol, o, out[i]);
+          for (int i = 0; i < Q; ++i) st(Dp + (long long)i * G.vol, os3[1 + BFLBM_SX(Vel::cx[i])], out[i]);
         }
         {
           if (MODE == 2) {
@@ -285,7 +287,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
           double out[Q];
           d_populations(mg, out);
 #pragma unroll
-          for (int i = 0; i < Q; ++i) st(Dp + (long long)(i + Q) * G.vol, o, out[i]);
+          for (int i = 0; i < Q; ++i) st(Dp + (long long)(i + Q) * G.vol, os3[1 + BFLBM_SX(Vel::cx[i])], out[i]);
         }
       }
     }

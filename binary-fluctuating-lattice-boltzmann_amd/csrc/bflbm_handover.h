@@ -240,7 +240,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
       const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
-      const unsigned o = oo[1 - Vel::cy[i]][1 - Vel::cx[i]];
+      const unsigned o = oo[1 - Vel::cy[i]][1 + BFLBM_PX(Vel::cx[i])];
       if (which != 2) f[i] = ld(b, o);
       if (which != 1) g[i] = ld(b + (long long)Q * G.vol, o);
     }
@@ -310,7 +310,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
           double rs = zero;
 #pragma unroll
           for (int i = 0; i < Q; ++i) {
-            unsigned o = hyo[1 - Vel::cy[i]] + hxo[1 - Vel::cx[i]];
+            unsigned o = hyo[1 - Vel::cy[i]] + hxo[1 + BFLBM_PX(Vel::cx[i])];
             asm volatile("" : "+v"(o));
             rs += ld(pl[1 - Vel::cz[i]] + (long long)(fl * Q + i) * G.vol, o);
           }
@@ -378,6 +378,8 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       double* __restrict__ Dp = D + (long long)pcw * G.plane;
       unsigned o = yo[1] + xo[1];
       asm volatile("" : "+v"(o));
+      unsigned os3[3] = { yo[1] + xo[0], o, yo[1] + xo[2] };       // store slots of populations with c_x = -1, 0, +1 (BFLBM_XSHIFT)
+      if (BFLBM_XSHIFT) { asm volatile("" : "+v"(os3[0])); asm volatile("" : "+v"(os3[2])); }
       SiteHydro Hy;
       SiteRecip R;
       d_site_recips(P, r, ph, R);
@@ -396,7 +398,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
         PopTerms T;
         d_population_terms(mom, T);
         double* __restrict__ Dk = Dp + (long long)(k * Q) * G.vol;
-        auto put = [&](int i, double v) { st(Dk + (long long)i * G.vol, o, v); };
+        auto put = [&](int i, double v) { st(Dk + (long long)i * G.vol, os3[1 + BFLBM_SX(Vel::cx[i])], v); };
         auto diag = [&](int g, int j) {          // population j of plane g (d_populations)
           return j == 0 ? T.B[g] + T.p[g] + T.q[g] + T.r[g] : j == 1 ? T.B[g] - T.p[g] - T.q[g] + T.r[g]
                : j == 2 ? T.B[g] + T.p[g] - T.q[g] - T.r[g] : T.B[g] - T.p[g] + T.q[g] - T.r[g]; };

@@ -12,6 +12,16 @@
 
 #include "bflbm_site.h"
 
+// Layout of the x direction.  BFLBM_XSHIFT 1 ("half-streamed"): population i of logical site x is stored at x + c_ix
+// (periodic), i.e. it is streamed in x when it is STORED and in y,z when it is pulled: every pull reads x-aligned row
+// segments (the line of the neighbouring tile that an x-shifted segment touches was 9 % of the reads) and
+// every store of a population with c_ix != 0 is shifted by one element instead.  Pure data movement: the same doubles.
+#ifndef BFLBM_XSHIFT
+#define BFLBM_XSHIFT 0
+#endif
+#define BFLBM_PX(cx) (BFLBM_XSHIFT ? 0 : -(cx))      /* x displacement of the pull of a population with c_x = cx */
+#define BFLBM_SX(cx) (BFLBM_XSHIFT ? (cx) : 0)       /* x displacement of its store */
+
 struct Geo {
   int nx, ny, nzs;     // storage extent (nzs includes the halo planes)
   int zwrap;           // 1: plane neighbours wrap modulo nzs (single slab)
@@ -64,7 +74,7 @@ __device__ __forceinline__ void pull_site(const double* __restrict__ S, const Ge
                                           double (&fs)[Q], double (&gs)[Q]) {
 #pragma unroll
   for (int i = 0; i < Q; ++i) {
-    const long long o = nb_off(I, -Vel::cx[i], -Vel::cy[i], -Vel::cz[i]);
+    const long long o = nb_off(I, BFLBM_PX(Vel::cx[i]), -Vel::cy[i], -Vel::cz[i]);
     fs[i] = S[(long long)i*G.vol + o];
     gs[i] = S[(long long)(i+Q)*G.vol + o];
   }
@@ -140,7 +150,7 @@ __device__ __forceinline__ void pull_site(const double* __restrict__ S, const Ge
 #pragma unroll
   for (int i = 0; i < Q; ++i) {
     const double* __restrict__ b = S + (long long)i*G.vol + I.pl[1 - Vel::cz[i]];
-    const unsigned o = I.o[1 - Vel::cy[i]][1 - Vel::cx[i]];
+    const unsigned o = I.o[1 - Vel::cy[i]][1 + BFLBM_PX(Vel::cx[i])];
     fs[i] = ld_sb(b, o);
     gs[i] = ld_sb(b + (long long)Q*G.vol, o);
   }
@@ -253,7 +263,7 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
     }
     d_populations(m, fs);
 #pragma unroll
-    for (int i = 0; i < Q; ++i) st_sb(Dp + (long long)i*G.vol, o, fs[i]);
+    for (int i = 0; i < Q; ++i) st_sb(Dp + (long long)i*G.vol, BFLBM_XSHIFT ? I.o[1][1 + BFLBM_SX(Vel::cx[i])] : o, fs[i]);
   }
   {
     double m[Q];
@@ -271,7 +281,7 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
     }
     d_populations(m, gs);
 #pragma unroll
-    for (int i = 0; i < Q; ++i) st_sb(Dp + (long long)(i+Q)*G.vol, o, gs[i]);
+    for (int i = 0; i < Q; ++i) st_sb(Dp + (long long)(i+Q)*G.vol, BFLBM_XSHIFT ? I.o[1][1 + BFLBM_SX(Vel::cx[i])] : o, gs[i]);
   }
 }
 
@@ -296,7 +306,7 @@ __global__ void __launch_bounds__(256) k_unstream(const double* __restrict__ N, 
   const long long o = I.row[1][1] + x;
 #pragma unroll
   for (int i = 0; i < Q; ++i) {
-    const long long src = nb_off(I, Vel::cx[i], Vel::cy[i], Vel::cz[i]);
+    const long long src = nb_off(I, BFLBM_XSHIFT ? 0 : Vel::cx[i], Vel::cy[i], Vel::cz[i]);   // the slot of site x - c_x: N_i there + c_i
     S[(long long)i*G.vol + o] = N[(long long)i*G.vol + src];
     S[(long long)(i+Q)*G.vol + o] = N[(long long)(i+Q)*G.vol + src];
   }
@@ -321,7 +331,7 @@ __global__ void __launch_bounds__(256) k_init(double* __restrict__ S, const doub
       const int pe = p + 1 + Vel::cz[i];
       if (mode == 1) r = rho_ext[pe];
       else {
-        const int xx = Vel::cx[i] > 0 ? xp : (Vel::cx[i] < 0 ? xm : x);
+        const int xx = BFLBM_XSHIFT ? x : (Vel::cx[i] > 0 ? xp : (Vel::cx[i] < 0 ? xm : x));
         const int yy = Vel::cy[i] > 0 ? yp : (Vel::cy[i] < 0 ? ym : y);
         r = rho_ext[(long long)pe*G.dplane + (long long)yy*G.nx + xx];
       }
