@@ -112,7 +112,9 @@ def test_config4_pair_of_1024x1024x64_slabs(pkg):
         assert np.array_equal(ha[comp], hr[comp]), comp
 
 
-@pytest.mark.parametrize("shape,init", [((128, 64, 48), ("droplet", 0.25)), ((256, 32, 24), ("stripe", 0.5))])
+@pytest.mark.parametrize("shape,init", [((128, 64, 48), ("droplet", 0.25)), ((256, 32, 24), ("stripe", 0.5)),
+                                        ((128, 8, 2), ("droplet", 0.3)), ((128, 8, 3), ("stripe", 0.5)), ((192, 12, 5), ("droplet", 0.3)),
+                                        ((128, 8, 9), ("droplet", 0.3))])
 def test_handover_schedule_tolerance_contract(pkg, shape, init):
     """Schedule 3 hands the tile-ring densities over from the previous step: the first step after an init
     pulls them (bit-identical to schedule 1); afterwards the ring sums have another fixed order, so the
@@ -128,7 +130,8 @@ def test_handover_schedule_tolerance_contract(pkg, shape, init):
     assert np.array_equal(fe, fh) and np.array_equal(ge, gh)
     (fe, ge), he = run("fused", 50)
     (fh, gh), hh = run("handover", 50)
-    assert not np.array_equal(fe, fh)                # the frames are in use
+    if shape[2] >= 8:
+        assert not np.array_equal(fe, fh)            # the frames are in use (a chunk of fewer than 4 planes has none)
     assert max(np.abs(fe - fh).max(), np.abs(ge - gh).max()) < 1e-14
     _tolerances(hh, he)
     (fh2, gh2), _ = run("handover", 50)
