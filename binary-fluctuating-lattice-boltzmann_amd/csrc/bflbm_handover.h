@@ -40,11 +40,15 @@
 #ifndef HO_EARLY
 #define HO_EARLY 0
 #endif
+#ifndef HO_FREG
+#define HO_FREG 0       // PIPE: 1 = the pending plane of fluid f stays in registers (only g waits in LDS)
+#endif
 template <int TY> struct HoLayout {
   static constexpr int TX = 64;
-  // slots of one fluid's frame (doubles)
-  static constexpr int EB = 0, ET = TX, EL = 2 * TX, ER = EL + (TY - 2);
-  static constexpr int OB = ER + (TY - 2), OT = OB + TX, OL = OT + TX, OR_ = OL + (TY + 2);
+  // slots of one fluid's frame (doubles): the four 64-entry rows first, each on its own 128-byte lines (they are stored
+  // and loaded by whole waves), the column entries (4*TY doubles, one line for TY = 4) behind them
+  static constexpr int EB = 0, ET = TX, OB = 2 * TX, OT = 3 * TX;
+  static constexpr int EL = 4 * TX, ER = EL + (TY - 2), OL = ER + (TY - 2), OR_ = OL + (TY + 2);
   static constexpr int FR = OR_ + (TY + 2);            // 4*TX + 4*TY: 272 (TY=4), 288 (TY=8) -- whole 128-byte lines
   static constexpr int REC = 2 * FR;                   // both fluids
 };
@@ -117,7 +121,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   static_assert(TY >= 4 && NPER <= 64 && 8 * TY <= 64, "tile shape");
   __shared__ double rp[4][2][LSZ];                     // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
   __shared__ double gl[Q][NT];                         // g populations of the previous plane
-  __shared__ double fl[PIPE ? Q : 1][PIPE ? NT : 1];   // PIPE: f populations of the previous plane (registers otherwise)
+  __shared__ double fl[(PIPE && !HO_FREG) ? Q : 1][(PIPE && !HO_FREG) ? NT : 1];   // PIPE: f populations of the previous plane (registers otherwise)
   __shared__ double exch[2][2][2][2][TX];              // [buf][fluid][side][0 edge row's own sum, 1 sum handed over by the row next to it][lane]
   __shared__ double accs[2][2][2][TX];                 // [stage][fluid][side][lane] z pipeline of the edge rows' own sums
   __shared__ double colacc[2][2][2][TY][6];            // [stage][fluid][side][row][kind] z pipeline of the column lanes
@@ -334,7 +338,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     }
     double mf[Q], jf[3];
     if (do_collide) {
-      if (PIPE) {
+      if (PIPE && !HO_FREG) {
         double pfl[Q];
 #pragma unroll
         for (int i = 0; i < Q; ++i) pfl[i] = fl[i][tid];
@@ -348,8 +352,10 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
 #pragma unroll
     for (int i = 0; i < Q; ++i) gl[i][tid] = cg[i];
     if (PIPE) {
+      if (!HO_FREG) {
 #pragma unroll
-      for (int i = 0; i < Q; ++i) fl[i][tid] = cf[i];
+        for (int i = 0; i < Q; ++i) fl[i][tid] = cf[i];
+      }
       // in flight while plane q-1 is collided; without a collision at this position both halves go now
       if (!HO_EARLY && q + 1 <= qb) {
         pull_plane(q + 1, nf, ng, hvn, HO_SPLIT ? 1 : 0);
@@ -457,7 +463,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       else           d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
       finish_fluid(mg, 1);
     }
-    if (!PIPE) {
+    if (!PIPE || HO_FREG) {
 #pragma unroll
       for (int i = 0; i < Q; ++i) pf[i] = cf[i];
     }
