@@ -130,3 +130,23 @@ def test_noisecovariance_notebook_statistic(pkg):
         assert abs(norm[a].var() - 0.0100) < 0.0015, norm[a].var()
     assert abs(1.00041 - 1.0) < 0.0065 and abs(0.00965 - 0.0100) < 0.0015     # the recorded reference values
     lbm.close()
+
+
+def test_equilibrium_fluctuations_at_256_cubed_with_the_default_schedule(pkg):
+    """configs[2] run as a user would (auto = the pipelined hand-over kernel with the generator inside): after 3000 steps of
+    the ideal mixture (alpha0 = 0, rho = phi = 1, tau = 1, kBT = 1e-5) the equal-site fluctuations sit at their equilibrium
+    values <d rho^2> = rho kBT / cs2 and <u_x^2> = kBT / rho (Mixture.ipynb cell 2's normalisations, k-integrated); 1.7e7
+    sites, correlated over a few cells: asserted within 1 %.  Mass is conserved to rounding."""
+    n, kBT = 256, 1e-5
+    lbm = pkg.BinaryLBM(n, n, n, params=pkg.default_params(kBT=kBT, alpha0=0.0, tau_f=1.0, tau_g=1.0))
+    assert lbm.resolved_schedule() == "handover"
+    lbm.LBM_init_mixture()
+    m0 = lbm.mass()
+    lbm.LBM_timestep(3000)
+    m1 = lbm.mass()
+    hb = lbm.LBM_hydrovars_density()
+    lbm.close()
+    assert np.isfinite(hb).all()
+    assert abs(m1[0] - m0[0]) <= 1e-12 * m0[0] and abs(m1[1] - m0[1]) <= 1e-12 * m0[1]
+    assert abs(hb[0].var() / (kBT * 3.0) - 1.0) < 0.01
+    assert abs((hb[2] ** 2).mean() / kBT - 1.0) < 0.01
