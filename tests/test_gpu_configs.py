@@ -174,3 +174,28 @@ def test_thermal_noise_in_the_pipelined_kernel(pkg, shape):
         assert np.abs(out["two_pass", 30][k] - out["handover", 30][k]).max() < 1e-13
     f = out["handover", 30][0]
     assert np.abs(f - f.mean(axis=(1, 2, 3), keepdims=True)).max() > 1e-6          # the noise is there
+
+
+def test_handover_random_cases(pkg):
+    """Seeded random lattices of full 64 x 4 tiles, inits, parameters and step counts: the hand-over schedule stays within
+    the north-star tolerances of the bit-exact fused schedule, single context and rings of 2-3 slabs alike."""
+    rng = np.random.default_rng(20261004)
+    for case in range(10):
+        nx = int(rng.choice([128, 192, 256]))
+        ny = int(rng.choice(np.arange(8, 44, 4)))
+        nz = int(rng.integers(4, 28))
+        steps = int(rng.integers(3, 30))
+        par = pkg.default_params(alpha0=float(rng.choice([0.0, 1.5, 2.5, 4.0])), tau_f=float(rng.choice([0.5, 0.8, 1.0])),
+                                 tau_g=float(rng.choice([0.5, 0.6, 1.0])), kappa=float(rng.choice([0.1, 1.0, 4.0])), rho_hi=float(rng.choice([1.0, 3.0])))
+        init = ("droplet", float(rng.uniform(0.05, 0.3))) if rng.random() < 0.6 else ("stripe", float(rng.uniform(0.3, 0.7)))
+        nslabs = int(rng.choice([1, 1, 2, 3])) if nz >= 12 else 1
+        out = {}
+        for sched in ("fused", "handover"):
+            l = (pkg.BinaryLBM(nx, ny, nz, params=par, schedule=sched) if nslabs == 1 or sched == "fused"
+                 else pkg.RingLBM(nx, ny, nz, nslabs=nslabs, params=par, schedule=sched))
+            getattr(l, "LBM_init_" + init[0])(init[1])
+            l.LBM_timestep(steps)
+            out[sched] = l.LBM_hydrovars()
+            l.close()
+        assert np.isfinite(out["handover"]).all(), (case, nx, ny, nz)
+        _tolerances(out["handover"], out["fused"])
