@@ -34,6 +34,12 @@
 
 #include "bflbm_fused.h"
 
+#ifndef HO_PEEL
+#define HO_PEEL 1
+#endif
+#ifndef HO_PROLOGUE_WAIT
+#define HO_PROLOGUE_WAIT 1
+#endif
 #ifndef HO_SPLIT
 #define HO_SPLIT 1      // PIPE: the g half of the next plane is requested after fluid f is finished (+2.9 % at 512^3, median of 5)
 #endif
@@ -260,10 +266,23 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     }
   };
   double nf[Q], ng[Q], hvn[2][4];                            // PIPE: the plane in flight
-  if (PIPE) pull_plane(qa - 1, nf, ng, hvn);
+  if (PIPE) {
+    pull_plane(qa - 1, nf, ng, hvn);
+    // The first plane is waited for here, outside the loop: the wait at the loop head is then computed from the
+    // back edge alone, where the stores of the previous position are younger than every load it needs, and no
+    // longer drains those stores (it was vmcnt(0), the join of this path and the back edge).
+    if (HO_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt and lgkmcnt untouched
+  }
 
   int it = 0;
-  for (int q = qa - 1; q <= qb; ++q, ++it) {
+  // One march position. COL / LDN say at compile time whether this position collides a plane and whether it
+  // requests the next one (-1: decided at run time). The pipelined kernel runs the two leading positions, the
+  // steady state and the last position as separate instances, so that the steady-state loop has a single path
+  // of memory operations: the compiler's wait at the loop head is then the one the back edge needs -- the
+  // loads, not the 19 stores issued after them (it was vmcnt(0): the join with the paths that end in loads).
+  auto position = [&](const int q, auto col_c, auto ldn_c) {
+    constexpr int COL = decltype(col_c)::value, LDN = decltype(ldn_c)::value;
+    const bool load_next = LDN < 0 ? (q + 1 <= qb) : (LDN != 0);
     const int slot = it & 3;
     const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
                                          S + (long long)wrapp(q + 1) * G.plane };
@@ -274,7 +293,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       for (int i = 0; i < Q; ++i) { cf[i] = nf[i]; cg[i] = ng[i]; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { hv[0][j] = hvn[0][j]; hv[1][j] = hvn[1][j]; }
-      if (HO_EARLY && q + 1 <= qb) {
+      if (HO_EARLY && load_next) {
         pull_plane(q + 1, nf, ng, hvn, HO_SPLIT ? 1 : 0);
         if (HO_SPLIT && !(q - 1 >= qa && q - 1 < qb)) pull_plane(q + 1, nf, ng, hvn, 2);
       }
@@ -310,16 +329,20 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
         const int hx = wrapx(x0 + rx - 1), hy = wrapy(y0 + ry - 1);
         const unsigned hxo[3] = { (unsigned)wrapx(hx - 1) * 8u, (unsigned)hx * 8u, (unsigned)wrapx(hx + 1) * 8u };
         const unsigned hyo[3] = { (unsigned)(wrapy(hy - 1) * G.pitch) * 8u, (unsigned)(hy * G.pitch) * 8u, (unsigned)(wrapy(hy + 1) * G.pitch) * 8u };
-        for (int fl = 0; fl < 2; ++fl) {
-          double rs = zero;
+        double t[2][Q];
 #pragma unroll
-          for (int i = 0; i < Q; ++i) {
-            unsigned o = hyo[1 - Vel::cy[i]] + hxo[1 + BFLBM_PX(Vel::cx[i])];
-            asm volatile("" : "+v"(o));
-            rs += ld(pl[1 - Vel::cz[i]] + (long long)(fl * Q + i) * G.vol, o);
-          }
-          rp[slot][fl][ry * LW + rx] = rs;
+        for (int i = 0; i < Q; ++i) {
+          unsigned o = hyo[1 - Vel::cy[i]] + hxo[1 + BFLBM_PX(Vel::cx[i])];
+          asm volatile("" : "+v"(o));
+          const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
+          t[0][i] = ld(b, o);
+          t[1][i] = ld(b + (long long)Q * G.vol, o);
         }
+        // all 38 requests are out before the first sum waits (left to itself the compiler issued one load, waited
+        // for it, added, and went on to the next: 38 memory latencies in a row at four positions of every chunk)
+        __builtin_amdgcn_sched_barrier(0);
+        rp[slot][0][ry * LW + rx] = density(t[0]);
+        rp[slot][1][ry * LW + rx] = density(t[1]);
       }
     }
     __syncthreads();
@@ -327,7 +350,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     finish(q - 3, (it & 1) ^ 1);
     // 3. collide plane q-1
     const int pc = q - 1;
-    const bool do_collide = (pc >= qa) && (pc < qb);
+    const bool do_collide = COL < 0 ? ((pc >= qa) && (pc < qb)) : (COL != 0);
     double mg[Q], jg[3];
     if (do_collide) {
       double pg[Q];
@@ -357,9 +380,8 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
         for (int i = 0; i < Q; ++i) fl[i][tid] = cf[i];
       }
       // in flight while plane q-1 is collided; without a collision at this position both halves go now
-      if (!HO_EARLY && q + 1 <= qb) {
+      if (!HO_EARLY && load_next) {
         pull_plane(q + 1, nf, ng, hvn, HO_SPLIT ? 1 : 0);
-        if (HO_SPLIT && !do_collide) pull_plane(q + 1, nf, ng, hvn, 2);     // the first two positions of a chunk collide nothing: both halves now
       }
     }
     if (do_collide) {
@@ -458,15 +480,30 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       if (MODE == 1) d_relax_generated(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn3, NA.sr, ntab, rst, R.cs4);
       else           d_relax<false>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, zn, R.cs4);
       finish_fluid(mf, 0);
-      if (PIPE && HO_SPLIT && q + 1 <= qb) pull_plane(q + 1, nf, ng, hvn, 2);   // the g half of the next plane: spreads the requests over the march position
+      if (PIPE && HO_SPLIT && load_next) pull_plane(q + 1, nf, ng, hvn, 2);   // the g half of the next plane: spreads the requests over the march position
       if (MODE == 1) d_relax_generated(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn3, NA.sp, ntab, rst, R.cs4);
       else           d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
       finish_fluid(mg, 1);
+    } else if (PIPE && HO_SPLIT && !HO_EARLY && load_next) {
+      // the first two positions of a chunk collide nothing: the g half goes now, and is waited for here (as in
+      // the prologue: keeps vmcnt(0) out of the loop head)
+      pull_plane(q + 1, nf, ng, hvn, 2);
+      if (HO_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
     }
     if (!PIPE || HO_FREG) {
 #pragma unroll
       for (int i = 0; i < Q; ++i) pf[i] = cf[i];
     }
+  };
+  using std::integral_constant;
+  if (PIPE && HO_PEEL) {
+    int q = qa - 1;                                          // qb >= qa + 1: both leading positions request a plane
+    for (int k = 0; k < 2; ++k, ++q, ++it) position(q, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+    for (; q < qb; ++q, ++it) position(q, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+    position(qb, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    ++it;
+  } else {
+    for (int q = qa - 1; q <= qb; ++q, ++it) position(q, integral_constant<int, -1>{}, integral_constant<int, -1>{});
   }
   // the last complete plane (qb-2) was finished at the last position; combine it across rows
   __syncthreads();
