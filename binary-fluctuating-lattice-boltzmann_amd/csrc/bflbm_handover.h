@@ -34,21 +34,6 @@
 
 #include "bflbm_fused.h"
 
-#ifndef HO_PEEL
-#define HO_PEEL 1
-#endif
-#ifndef HO_PROLOGUE_WAIT
-#define HO_PROLOGUE_WAIT 1
-#endif
-#ifndef HO_SPLIT
-#define HO_SPLIT 1      // PIPE: the g half of the next plane is requested after fluid f is finished (+2.9 % at 512^3, median of 5)
-#endif
-#ifndef HO_EARLY
-#define HO_EARLY 0
-#endif
-#ifndef HO_FREG
-#define HO_FREG 0       // PIPE: 1 = the pending plane of fluid f stays in registers (only g waits in LDS)
-#endif
 template <int TY> struct HoLayout {
   static constexpr int TX = 64;
   // slots of one fluid's frame (doubles): the four 64-entry rows first, each on its own 128-byte lines (they are stored
@@ -111,13 +96,15 @@ __device__ __forceinline__ double ho_shl(double v) {   // value of lane+1 (trave
   return __hiloint2double(hi, lo);
 }
 
-// PIPE = false: two workgroups per CU at two waves per SIMD (256 registers; the frame producer spills).
-// PIPE = true: ONE workgroup per CU at one wave per SIMD (512 registers per lane, AGPRs included, 160 KB of LDS): the
-// pending plane of BOTH fluids waits in LDS, and the loads of plane q+1 are issued before plane q-1 is collided, so
-// that memory latency runs under the arithmetic inside one wave instead of between waves.
+// ONE workgroup per CU at one wave per SIMD (512 registers per lane, AGPRs included, 160 KB of LDS): the pending
+// plane of BOTH fluids waits in LDS, and the loads of plane q+1 are issued before plane q-1 is collided -- the f half
+// before fluid f is relaxed, the g half after it is finished -- so that memory latency runs under the arithmetic
+// inside one wave instead of between waves.  (At two waves per SIMD the frame producer spills 59-90 registers; that
+// form, and the variants that kept the f plane in registers or requested the next plane before the density sums,
+// were measured and removed: DESIGN.md section 3.1b.)
 // MODE 0: zero noise; MODE 1: generated thermal noise (csrc/bflbm_rng.h), drawn where it is added.
-template <int TY, bool PIPE, int MODE>
-__global__ void __launch_bounds__(64 * TY, PIPE ? 1 : 2)
+template <int TY, int MODE>
+__global__ void __launch_bounds__(64 * TY, 1)
 k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParams P, FusedGrid F, HoGrid Hg, uint32_t noise_index) {
   using L = HoLayout<TY>;
   constexpr int TX = 64, NT = TX * TY, NW = TY;
@@ -127,7 +114,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   static_assert(TY >= 4 && NPER <= 64 && 8 * TY <= 64, "tile shape");
   __shared__ double rp[4][2][LSZ];                     // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
   __shared__ double gl[Q][NT];                         // g populations of the previous plane
-  __shared__ double fl[(PIPE && !HO_FREG) ? Q : 1][(PIPE && !HO_FREG) ? NT : 1];   // PIPE: f populations of the previous plane (registers otherwise)
+  __shared__ double fl[Q][NT];                         // f populations of the previous plane
   __shared__ double exch[2][2][2][2][TX];              // [buf][fluid][side][0 edge row's own sum, 1 sum handed over by the row next to it][lane]
   __shared__ double accs[2][2][2][TX];                 // [stage][fluid][side][lane] z pipeline of the edge rows' own sums
   __shared__ double colacc[2][2][2][TY][6];            // [stage][fluid][side][row][kind] z pipeline of the column lanes
@@ -203,9 +190,6 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   // planes whose frames are complete: all three source planes collided by this workgroup
   const int fa = qa + 1, fb = qb - 2;                        // [fa, fb]
 
-  double pf[Q];
-#pragma unroll
-  for (int i = 0; i < Q; ++i) pf[i] = 0.;
   double anb[2][2] = {{0., 0.}, {0., 0.}};                   // [fluid][stage] z pipeline of the row's travelling sum
 
   // finish the frames of plane tpf from what the previous march position left in LDS (after a barrier)
@@ -265,41 +249,30 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       }
     }
   };
-  double nf[Q], ng[Q], hvn[2][4];                            // PIPE: the plane in flight
-  if (PIPE) {
-    pull_plane(qa - 1, nf, ng, hvn);
-    // The first plane is waited for here, outside the loop: the wait at the loop head is then computed from the
-    // back edge alone, where the stores of the previous position are younger than every load it needs, and no
-    // longer drains those stores (it was vmcnt(0), the join of this path and the back edge).
-    if (HO_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt and lgkmcnt untouched
-  }
+  double nf[Q], ng[Q], hvn[2][4];                            // the plane in flight
+  pull_plane(qa - 1, nf, ng, hvn);
+  // The first plane is waited for here, outside the loop: the wait at the loop head is then computed from the
+  // back edge alone, where the stores of the previous position are younger than every load it needs, and no
+  // longer drains those stores (it was vmcnt(0), the join of this path and the back edge).
+  __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0), expcnt and lgkmcnt untouched
 
   int it = 0;
-  // One march position. COL / LDN say at compile time whether this position collides a plane and whether it
-  // requests the next one (-1: decided at run time). The pipelined kernel runs the two leading positions, the
-  // steady state and the last position as separate instances, so that the steady-state loop has a single path
-  // of memory operations: the compiler's wait at the loop head is then the one the back edge needs -- the
-  // loads, not the 19 stores issued after them (it was vmcnt(0): the join with the paths that end in loads).
+  // One march position. The two template flags say at compile time whether this position collides a plane and whether it
+  // requests the next one. The two leading positions, the steady state and the last position are separate
+  // instances, so that the steady-state loop has a single path of memory operations: the compiler's wait at the
+  // loop head is then the one the back edge needs -- the loads, not the 19 stores issued after them (it was
+  // vmcnt(0): the join with the paths that end in loads).
   auto position = [&](const int q, auto col_c, auto ldn_c) {
-    constexpr int COL = decltype(col_c)::value, LDN = decltype(ldn_c)::value;
-    const bool load_next = LDN < 0 ? (q + 1 <= qb) : (LDN != 0);
+    constexpr bool do_collide = decltype(col_c)::value, load_next = decltype(ldn_c)::value;
     const int slot = it & 3;
     const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
                                          S + (long long)wrapp(q + 1) * G.plane };
-    // 1. plane q: pulled now, or (PIPE) pulled while the previous plane was collided
+    // 1. plane q: pulled while the previous plane was collided
     double cf[Q], cg[Q], hv[2][4];
-    if (PIPE) {
 #pragma unroll
-      for (int i = 0; i < Q; ++i) { cf[i] = nf[i]; cg[i] = ng[i]; }
+    for (int i = 0; i < Q; ++i) { cf[i] = nf[i]; cg[i] = ng[i]; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { hv[0][j] = hvn[0][j]; hv[1][j] = hvn[1][j]; }
-      if (HO_EARLY && load_next) {
-        pull_plane(q + 1, nf, ng, hvn, HO_SPLIT ? 1 : 0);
-        if (HO_SPLIT && !(q - 1 >= qa && q - 1 < qb)) pull_plane(q + 1, nf, ng, hvn, 2);
-      }
-    } else {
-      pull_plane(q, cf, cg, hv);
-    }
+    for (int j = 0; j < 4; ++j) { hv[0][j] = hvn[0][j]; hv[1][j] = hvn[1][j]; }
     const bool ring_from_frames = Hg.use_frames && q >= fa && q <= fb;       // uniform over the workgroup
     double zero = 0.0;
     asm volatile("" : "+v"(zero));
@@ -350,7 +323,6 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     finish(q - 3, (it & 1) ^ 1);
     // 3. collide plane q-1
     const int pc = q - 1;
-    const bool do_collide = COL < 0 ? ((pc >= qa) && (pc < qb)) : (COL != 0);
     double mg[Q], jg[3];
     if (do_collide) {
       double pg[Q];
@@ -361,29 +333,18 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     }
     double mf[Q], jf[3];
     if (do_collide) {
-      if (PIPE && !HO_FREG) {
-        double pfl[Q];
+      double pfl[Q];
 #pragma unroll
-        for (int i = 0; i < Q; ++i) pfl[i] = fl[i][tid];
-        d_moments(pfl, mf);
-        d_momentum(pfl, jf);
-      } else {
-        d_moments(pf, mf);
-        d_momentum(pf, jf);
-      }
+      for (int i = 0; i < Q; ++i) pfl[i] = fl[i][tid];
+      d_moments(pfl, mf);
+      d_momentum(pfl, jf);
     }
 #pragma unroll
     for (int i = 0; i < Q; ++i) gl[i][tid] = cg[i];
-    if (PIPE) {
-      if (!HO_FREG) {
 #pragma unroll
-        for (int i = 0; i < Q; ++i) fl[i][tid] = cf[i];
-      }
-      // in flight while plane q-1 is collided; without a collision at this position both halves go now
-      if (!HO_EARLY && load_next) {
-        pull_plane(q + 1, nf, ng, hvn, HO_SPLIT ? 1 : 0);
-      }
-    }
+    for (int i = 0; i < Q; ++i) fl[i][tid] = cf[i];
+    // the f half of the next plane: in flight while plane q-1 is collided
+    if (load_next) pull_plane(q + 1, nf, ng, hvn, 1);
     if (do_collide) {
       const int sl[3] = { (it - 2) & 3, (it - 1) & 3, it & 3 };
       const double r = rp[sl[1]][0][lown], ph = rp[sl[1]][1][lown];
@@ -480,30 +441,24 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       if (MODE == 1) d_relax_generated(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn3, NA.sr, ntab, rst, R.cs4);
       else           d_relax<false>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, zn, R.cs4);
       finish_fluid(mf, 0);
-      if (PIPE && HO_SPLIT && load_next) pull_plane(q + 1, nf, ng, hvn, 2);   // the g half of the next plane: spreads the requests over the march position
+      if (load_next) pull_plane(q + 1, nf, ng, hvn, 2);       // the g half of the next plane: spreads the requests over the march position (+2.9 % at 512^3)
       if (MODE == 1) d_relax_generated(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn3, NA.sp, ntab, rst, R.cs4);
       else           d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
       finish_fluid(mg, 1);
-    } else if (PIPE && HO_SPLIT && !HO_EARLY && load_next) {
+    } else if (load_next) {
       // the first two positions of a chunk collide nothing: the g half goes now, and is waited for here (as in
       // the prologue: keeps vmcnt(0) out of the loop head)
       pull_plane(q + 1, nf, ng, hvn, 2);
-      if (HO_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
-    }
-    if (!PIPE || HO_FREG) {
-#pragma unroll
-      for (int i = 0; i < Q; ++i) pf[i] = cf[i];
+      __builtin_amdgcn_s_waitcnt(0x0F70);
     }
   };
-  using std::integral_constant;
-  if (PIPE && HO_PEEL) {
+  using std::bool_constant;
+  {
     int q = qa - 1;                                          // qb >= qa + 1: both leading positions request a plane
-    for (int k = 0; k < 2; ++k, ++q, ++it) position(q, integral_constant<int, 0>{}, integral_constant<int, 1>{});
-    for (; q < qb; ++q, ++it) position(q, integral_constant<int, 1>{}, integral_constant<int, 1>{});
-    position(qb, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    for (int k = 0; k < 2; ++k, ++q, ++it) position(q, bool_constant<false>{}, bool_constant<true>{});
+    for (; q < qb; ++q, ++it) position(q, bool_constant<true>{}, bool_constant<true>{});
+    position(qb, bool_constant<true>{}, bool_constant<false>{});
     ++it;
-  } else {
-    for (int q = qa - 1; q <= qb; ++q, ++it) position(q, integral_constant<int, -1>{}, integral_constant<int, -1>{});
   }
   // the last complete plane (qb-2) was finished at the last position; combine it across rows
   __syncthreads();
@@ -538,9 +493,7 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
   F.pa = pa; F.pb = pb;
   const int np = pb - pa;
   static const int want_env = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 0; }();
-  // two 256-thread workgroups are resident per CU (LDS and registers), so a round is 2 x ncu workgroups
-  static const bool pipe_slots = [] { const char* e = getenv("BFLBM_HO_PIPE"); return e ? atoi(e) != 0 : true; }();
-  const int slots = (g_fused_ncu > 0 ? g_fused_ncu : 256) * ((TY == 4 && !pipe_slots && mode == 0) ? 2 : 1);
+  const int slots = g_fused_ncu > 0 ? g_fused_ncu : 256;        // one workgroup per CU
   static const int min_slab_rounds = [] { const char* e = getenv("BFLBM_SLAB_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
   const int maxchunks = std::max(1, np / 4);                     // a chunk shorter than 4 planes has no complete frame
   int nchunks;
@@ -571,11 +524,9 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
   Hg.fplane = (long long)F.ncols * HoLayout<TY>::REC;
   Hg.use_frames = (sig_in.step == steps - 1 && sig_in.same_geometry(sig_out)) ? 1 : 0;
   dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
-  static const bool pipe = [] { const char* e = getenv("BFLBM_HO_PIPE"); return e ? atoi(e) != 0 : true; }();
   const uint32_t nidx = (uint32_t)steps;
-  if (mode == 1)  hipLaunchKernelGGL((k_fused_ho<TY, true, 1>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);   // noise only in the pipelined form
-  else if (pipe)  hipLaunchKernelGGL((k_fused_ho<TY, true, 0>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
-  else            hipLaunchKernelGGL((k_fused_ho<TY, false, 0>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
+  if (mode == 1) hipLaunchKernelGGL((k_fused_ho<TY, 1>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
+  else           hipLaunchKernelGGL((k_fused_ho<TY, 0>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
   return hipGetLastError() != hipSuccess;
 }
 

@@ -6,7 +6,7 @@ import collections, re, sys
 L = open(sys.argv[1]).read().split('\n')
 modes = [int(sys.argv[2])] if len(sys.argv) > 2 else [0, 1]
 for mode in modes:
-    start = [i for i, l in enumerate(L) if re.match(r'^_Z10k_fused_hoILi4ELb1ELi%dE.*:' % mode, l)][0]
+    start = [i for i, l in enumerate(L) if re.match(r'^_Z10k_fused_hoILi4ELi%dE.*:' % mode, l)][0]
     end = [i for i in range(start, len(L)) if 's_endpgm' in L[i]][0]
     body = L[start:end]
     lab = {}
