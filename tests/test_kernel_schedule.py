@@ -1,0 +1,61 @@
+"""The compiled schedule of the hand-over kernel (no GPU needed: hipcc cross-compiles gfx950).
+
+With one wave per SIMD nothing hides a conservative wait, and two faults of exactly that kind were found in the
+generated code of this kernel ("Two faults in the generated schedule"): a `vmcnt(0)` at the
+head of the march loop that drained the stores of every position, and a pulled ring scheduled as 38 load-wait-add
+triples.  Neither shows in the source, so the properties are pinned on the assembly here."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "binary-fluctuating-lattice-boltzmann_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm") / "bflbm.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-w",
+                    "--cuda-device-only", "-S", "-o", str(out), "bflbm.hip"], cwd=CSRC, check=True, timeout=600)
+    return out.read_text().split("\n")
+
+
+def _kernel(lines, mode):
+    start = [i for i, l in enumerate(lines) if re.match(r"^_Z10k_fused_hoILi4ELi%dE.*:" % mode, l)][0]
+    end = [i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end")][0]
+    meta = "\n".join(lines[end:end + 120])
+    return lines[start:end], meta
+
+
+def _steady_loop(body):
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    loops = []
+    for i, l in enumerate(body):
+        m = re.match(r"\s+s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loops.append((labels[m.group(1)], i))
+    # the steady-state loop is the innermost loop that both loads and stores populations
+    cands = [lp for lp in loops
+             if sum("global_store" in l for l in body[lp[0]:lp[1]]) >= 38 and sum("global_load" in l for l in body[lp[0]:lp[1]]) >= 38]
+    return min(cands, key=lambda lp: lp[1] - lp[0])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_handover_kernel_schedule(device_asm, mode):
+    body, meta = _kernel(device_asm, mode)
+    assert re.search(r"; ScratchSize: 0\b", meta), "the hand-over kernel spills to scratch"
+    lo, hi = _steady_loop(body)
+    waits = [(i, int(re.search(r"vmcnt\((\d+)\)", body[i]).group(1))) for i in range(lo, hi) if "s_waitcnt" in body[i] and "vmcnt" in body[i]]
+    first_store = min(i for i in range(lo, hi) if "global_store" in body[i])
+    first_load = min(i for i in range(lo, hi) if "global_load" in body[i])
+    head = [w for i, w in waits if i < min(first_store, first_load)]
+    # the head waits for the loads of the previous position only: the 19 stores of fluid g stay in flight
+    assert head and min(head) >= 19, f"loop head drains the stores again: {head}"
+    # the pulled ring of the chunk-boundary planes is one batch: its waits count down once, so vmcnt(0) appears once
+    assert sum(1 for _, w in waits if w == 0) <= 1, [w for _, w in waits]
