@@ -107,11 +107,10 @@ template <int TY, int MODE>
 __global__ void __launch_bounds__(64 * TY, 1)
 k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParams P, FusedGrid F, HoGrid Hg, uint32_t noise_index) {
   using L = HoLayout<TY>;
-  constexpr int TX = 64, NT = TX * TY, NW = TY;
+  constexpr int TX = 64, NT = TX * TY;
   constexpr int LW = TX + 2, LSZ = (TX + 2) * (TY + 2);
   constexpr int NRING = 2 * (TX + 2) + 2 * TY;
-  constexpr int NPER = (NRING + NW - 1) / NW;          // ring sites per wave (frame path)
-  static_assert(TY >= 4 && NPER <= 64 && 8 * TY <= 64, "tile shape");
+  static_assert(TY >= 4 && 4 + 2 * TY <= 64 && 8 * TY <= 64, "tile shape");
   __shared__ double rp[4][2][LSZ];                     // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
   __shared__ double gl[Q][NT];                         // g populations of the previous plane
   __shared__ double fl[Q][NT];                         // f populations of the previous plane
@@ -150,17 +149,18 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   const bool col_lane = (tx == 0) || (tx == TX - 1);
   const int side_x = (tx == 0) ? 0 : 1;
   const unsigned tile_rec = (unsigned)((tiy * F.ntx + tix) * L::REC) * 8u;     // byte offset of this tile's frame in a plane
-  // ---- ring site of this thread when the ring comes from frames: lanes 0..NPER-1 of every wave, both fluids
-  const int rtask = ty * NPER + lane;
-  const bool has_rtask = lane < NPER && rtask < NRING;
+  // ---- ring site of this thread when the ring comes from frames, both fluids.  Wave 0 takes the 64 sites below
+  // the tile, wave 1 the 64 above it: their two pieces (E of the neighbouring tile, O of the own one) are whole
+  // 512-byte frame rows, four full lines per load.  The 4 corners and 2*TY column sites, which have up to four
+  // pieces in scattered places, go to lanes of wave 2.  (Spread evenly over the four waves, every wave issued all
+  // eight frame loads on parts of those rows: twice the instructions and half again the line requests.)
+  const bool has_rtask = ty < 2 || (ty == 2 && lane < 4 + 2 * TY);
   int hlx = 0, hly = 0;
-  if (has_rtask) {
-    const int r = rtask;
-    if (r < TX + 2) { hlx = r; hly = 0; }
-    else if (r < 2 * (TX + 2)) { hlx = r - (TX + 2); hly = TY + 1; }
-    else if (r < 2 * (TX + 2) + TY) { hlx = 0; hly = r - 2 * (TX + 2) + 1; }
-    else { hlx = TX + 1; hly = r - 2 * (TX + 2) - TY + 1; }
-  }
+  if (ty == 0) { hlx = lane + 1; hly = 0; }
+  else if (ty == 1) { hlx = lane + 1; hly = TY + 1; }
+  else if (ty == 2 && lane < 4) { hlx = (lane & 1) ? TX + 1 : 0; hly = (lane & 2) ? TY + 1 : 0; }
+  else if (ty == 2 && lane < 4 + TY) { hlx = 0; hly = lane - 4 + 1; }
+  else if (ty == 2 && lane < 4 + 2 * TY) { hlx = TX + 1; hly = lane - 4 - TY + 1; }
   const int lhalo = hly * LW + hlx;
   // the frames that hold a piece of this ring site: the owner's E and the O of every other tile around it
   unsigned fo[4] = {0u, 0u, 0u, 0u};
