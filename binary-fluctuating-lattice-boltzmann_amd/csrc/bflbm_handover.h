@@ -290,8 +290,8 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       }
     } else {
       rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg);
-      // pulled ring (chunk-boundary planes, first step): threads 0..NRING-1 pull one ring site, fluid after
-      // fluid (wave-uniform base + 32-bit lane offset, like the own loads); a rare path, kept small
+      // pulled ring (chunk-boundary planes, first step): threads 0..NRING-1 pull one ring site, both fluids in one
+      // batch of 38 loads (wave-uniform base + 32-bit lane offset, like the own loads); a rare path
       if (tid < NRING) {
         const int r = tid;
         int rx, ry;
