@@ -63,6 +63,8 @@ SIGNATURES = {
     "bflbm_download_fg": (ctypes.c_int, [_vp, _vp, _vp, _P(Fab)]),
     "bflbm_step": (ctypes.c_int, [_vp, ctypes.c_int]),
     "bflbm_step_count": (ctypes.c_int, [_vp, _P(ctypes.c_longlong)]),
+    "bflbm_set_step_count": (ctypes.c_int, [_vp, ctypes.c_longlong]),
+    "bflbm_ring_set_step_count": (ctypes.c_int, [_vp, ctypes.c_longlong]),
     "bflbm_step_boundary": (ctypes.c_int, [_vp]),
     "bflbm_step_interior": (ctypes.c_int, [_vp]),
     "bflbm_step_finish": (ctypes.c_int, [_vp]),

@@ -80,6 +80,10 @@ int main(int argc, char* argv[]) {
     std::printf("Loading in last frame checkpoint files....\n");
     if (!bflbm::LoadSingleMultiFab(bflbm::Concatenate(std::string(restart_from) + "/f_checkpoint", rstep), f_last_frame) ||
         !bflbm::LoadSingleMultiFab(bflbm::Concatenate(std::string(restart_from) + "/g_checkpoint", rstep), g_last_frame)) return 3;
+    if (kBT != 0. && !std::getenv("LBM_RESTART_NOISE_FROM_ZERO")) { // continue the noise stream at the checkpoint's step (restart == uninterrupted run)
+      bflbm::set_restart_step(rstep);
+      std::printf("noise index continues at step %d\n", rstep);
+    }
     LBM_init(geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs, f_last_frame, g_last_frame, rho_eq, phi_eq, rhot_eq, com_ref);
   } else
   if (system == "mixture")      LBM_init_mixture(geom, fold, gold, hydrovs, hydrovsbar, fnoisevs, gnoisevs, rho_eq, phi_eq, rhot_eq);

@@ -102,6 +102,7 @@ struct bflbm_ctx {
   long long steps = 0;
   int schedule = 2;              // 0 two-pass, 1 fused plane-marching (pulled ring), 2 auto (default), 3 fused with density hand-over
   double* frames[2] = {nullptr, nullptr};   // schedule 3: tile-boundary density frames of S[0], S[1] (bflbm_handover.h)
+  bool frames_unavailable = false;          // their allocation failed once: auto stays on the bit-exact schedules
   HoSig fsig[2][2];              // [state buffer][0 interior sweep, 1 boundary pairs]: the launch that wrote the frames
   bool step_open = false;
   bool density_valid = false;   // rho/phi arrays hold the densities of the resident state
@@ -174,10 +175,21 @@ int launch_collide(bflbm_ctx* c, int pa, int pb) {
   return 0;
 }
 
-int ensure_frames(bflbm_ctx* c) {
+// Frames of schedule 3: 2 x nzs x ntiles x 544 doubles = 5.6 % of the state (4.6 GB at 512^3).  An explicit request for
+// schedule 3 fails loudly when they cannot be allocated; `auto` remembers the failure and stays on the bit-exact
+// schedules (a lattice that fitted in HBM before the hand-over existed keeps running).
+int ensure_frames(bflbm_ctx* c, bool quiet = false) {
   if (c->frames[0]) return 0;
+  if (c->frames_unavailable) return quiet ? 1 : fail("hand-over frames could not be allocated earlier (out of device memory)");
   const size_t nb = handover_frame_doubles(c->G) * sizeof(double);
-  HIP_TRY(hipMalloc((void**)&c->frames[0], 2 * nb));
+  static const size_t fail_above = [] { const char* e = getenv("BFLBM_DEBUG_FRAMES_LIMIT"); return e ? (size_t)atoll(e) : (size_t)0; }();   // test hook
+  hipError_t e = (fail_above && 2 * nb > fail_above) ? hipErrorOutOfMemory : hipMalloc((void**)&c->frames[0], 2 * nb);
+  if (e != hipSuccess) {
+    c->frames[0] = nullptr;
+    (void)hipGetLastError();                                     // clear the sticky error
+    c->frames_unavailable = true;
+    return quiet ? 1 : fail("hand-over frames: %s (%zu bytes)", hipGetErrorString(e), 2 * nb);
+  }
   c->frames[1] = c->frames[0] + handover_frame_doubles(c->G);
   c->bytes += 2 * nb;
   return 0;
@@ -198,23 +210,33 @@ int launch_fused(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
                       (uint32_t)c->steps, c->inject ? 2 : (c->dp.noise_on ? 1 : 0), c->stream, pair_len) ? fail("fused launch failed: %s", hipGetErrorString(hipGetLastError())) : 0;
 }
 
-// auto: the fused kernel is the faster one at zero noise (one HBM pass); with thermal noise the step
-// is VALU-bound (Philox + Box-Muller) and the independent 256-thread workgroups of the two-pass
-// schedule use the vector units better (measured 4670-4810 vs 4100-4290 MLUPS at 256^3).
+// The range of model parameters inside which `auto` uses the hand-over kernel.  Schedule 3 differs from the reference's
+// doubles by a re-ordered sum of 19 numbers at tile-edge sites, i.e. by what a one-ulp change of the state does, and
+// what becomes of that is the trajectory's own conditioning: measured against the oracle (tools/ho_stress.py, DESIGN.md
+// section 3.1c) the difference equals the oracle's own response to a one-ulp perturbation case by case, which is inside
+// the north-star tolerance wherever the reference run is stable and unbounded where the reference itself diverges
+// (alpha0 = 4 with rho_hi = 3: NaN within 10-40 steps on the CPU path too).  Those diverging runs all have an
+// interaction strength alpha0 (rho_hi + rho_lo) >= 7.5; every parameter set the reference ships or its notebooks record
+// has <= 5.1 (header defaults 4 x 1, Surface_Tension.ipynb 1.5 x 3 and 1.7 x 3).  `auto` stays bit-exact above 6.
+inline bool handover_contract_params(const bflbm_params& p) {
+  return std::fabs(p.alpha0) * (std::fabs(p.rho_hi) + std::fabs(p.rho_lo)) <= 6.0;
+}
+
+// 0 two-pass, 1 fused (pulled ring), 3 hand-over.  The bit-exact choice is 1 at zero noise and 0 with noise.
+// auto (2): the pipelined hand-over kernel wherever the lattice has full 64 x 4 tiles with distinct neighbours (it
+// generates thermal noise itself but takes no injected noise), the parameters are inside the range above and the
+// frames fit in memory; BFLBM_AUTO_EXACT=1 keeps auto on the bit-exact schedules with and without noise.
 inline int resolved_schedule(const bflbm_ctx* c) {
   if (ref_active(c)) return 0;                   // needs the densities and their centre of mass first
   const bool noisy = c->dp.noise_on || c->inject;
-  // the hand-over kernel needs full 64 x TY tiles with distinct neighbours; it generates thermal noise itself
-  // (pipelined form) but takes no injected noise
-  if (c->schedule == 3) return c->inject ? 0 : (handover_ok(c->G) ? 3 : (noisy ? 0 : 1));
+  const int exact = noisy ? 0 : 1;
+  if (c->schedule == 3) return (!c->inject && handover_ok(c->G)) ? 3 : exact;
   if (c->schedule != 2) return c->schedule;
   static const int auto_noise_fused = [] { const char* e = getenv("BFLBM_AUTO_NOISE_HANDOVER"); return e ? atoi(e) != 0 : true; }();
-  if (noisy) return (!c->inject && auto_noise_fused && handover_ok(c->G)) ? 3 : 0;
-  // zero noise: the pipelined hand-over kernel where the lattice has full 64 x 4 tiles (+3-5 % over schedule 1 at
-  // 256^3 / 512^3, results within the north-star tolerance); BFLBM_AUTO_EXACT=1 keeps auto on
-  // the bit-exact schedule 1
   static const int auto_exact = [] { const char* e = getenv("BFLBM_AUTO_EXACT"); return e && atoi(e) != 0; }();
-  return (handover_ok(c->G) && !auto_exact) ? 3 : 1;
+  if (auto_exact || c->inject || c->frames_unavailable || !handover_ok(c->G) || !handover_contract_params(c->prm)) return exact;
+  if (noisy && !auto_noise_fused) return 0;
+  return 3;
 }
 
 // the slab's own planes are [H, H+nzl)
@@ -587,6 +609,7 @@ int bflbm_step_boundary(bflbm_ctx* c) {
   if (c->step_open) return fail("step already open");
   HIP_TRY(hipSetDevice(c->dom.device));
   if (prepare_ref(c)) return 1;
+  if (c->schedule == 2 && resolved_schedule(c) == 3) (void)ensure_frames(c, true);   // auto: falls back when they do not fit
   c->step_open = true;
   const int lo = own_lo(c), hi = own_hi(c);
   if (c->G.zwrap) return 0;                      // single slab: everything is "interior"
@@ -646,6 +669,19 @@ int bflbm_step(bflbm_ctx* c, int nsteps) {
 int bflbm_step_count(const bflbm_ctx* c, long long* n) {
   if (!c || !n) return fail("null argument");
   *n = c->steps;
+  return 0;
+}
+
+// The step counter is the noise index of the counter-based generator.  A restart from a kBT > 0 checkpoint sets it
+// to the checkpoint's absolute step (main_run_job.cpp:80 step_continue) so that the continued run draws fresh
+// normals instead of replaying the first segment's.
+int bflbm_set_step_count(bflbm_ctx* c, long long n) {
+  if (!c) return fail("null context");
+  if (n < 0) return fail("bflbm_set_step_count: negative step count");
+  if (c->step_open) return fail("bflbm_set_step_count inside an open step");
+  if (c->ref_kind_step == c->steps) c->ref_kind_step = n;
+  c->steps = n;
+  for (auto& b : c->fsig) for (auto& sg : b) sg = HoSig();     // frames are keyed by the step that wrote them
   return 0;
 }
 
@@ -1060,6 +1096,12 @@ int bflbm_ring_commit_upload(bflbm_ring* r, int reset) {
   for (bflbm_ctx* c : r->ctx) if (bflbm_commit_upload(c, reset)) return 1;
   if (ring_exchange(r, BFLBM_HALO_STATE) || ring_join(r)) return 1;
   return bflbm_ring_sync(r);
+}
+
+int bflbm_ring_set_step_count(bflbm_ring* r, long long n) {
+  if (!r) return fail("null ring");
+  for (bflbm_ctx* c : r->ctx) if (bflbm_set_step_count(c, n)) return 1;
+  return 0;
 }
 
 int bflbm_ring_com_sums(bflbm_ring* r, double sums[4]);

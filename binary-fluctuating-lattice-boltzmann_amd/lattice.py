@@ -222,6 +222,10 @@ class BinaryLBM(_DropletMixin):
         check(self.lib.bflbm_step_count(self._h, ctypes.byref(n)))
         return n.value
 
+    def set_steps_done(self, n):
+        """Absolute step of the resident state = noise index of the next step (restart from a kBT > 0 checkpoint)."""
+        check(self.lib.bflbm_set_step_count(self._h, int(n)))
+
     # -- state and per-step fields -------------------------------------------------------------
     def populations(self, f=None, g=None, fab=None):
         """fold, gold valid cells (post-stream state of the last completed step)."""
@@ -470,6 +474,9 @@ class RingLBM(_DropletMixin):
     @property
     def steps_done(self):
         return self.slabs[0].steps_done
+
+    def set_steps_done(self, n):
+        check(self.lib.bflbm_ring_set_step_count(self._h, int(n)))
 
 
 def rng_site_normals(seed, site, noise_index):

@@ -150,6 +150,11 @@ def main(argv=None):
         g0, _ = pf.read_plotfile(checkpoint_name(paths["chk_g"], a.step_continue, a.alpha0, chk_temp, n))
         print("Loading in last frame checkpoint files....")
         lbm.LBM_init(np.ascontiguousarray(f0), np.ascontiguousarray(g0))
+        if noise and not a.continue_from_nonfluct:
+            # the checkpoint already carries a fluctuating run: continue the noise stream at its absolute step instead of
+            # replaying the normals of steps 1..nsteps (the step counter is the generator's noise index)
+            lbm.set_steps_done(a.step_continue)
+            print("noise index continues at step %d (this segment draws indices %d..%d)" % (a.step_continue, a.step_continue, a.step_continue + a.nsteps - 1))
     elif a.system == "mixture":
         print("Init mixture system ...")
         lbm.LBM_init_mixture()

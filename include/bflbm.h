@@ -91,14 +91,22 @@ int bflbm_get_params(const bflbm_ctx* c, bflbm_params* p);
  * external == 0: go back to the context's own non-blocking stream (hip_stream ignored). */
 int bflbm_set_stream(bflbm_ctx* c, void* hip_stream, int external);
 
-/* Kernel schedule: 0 = two-pass (density pass + collide pass), 1 = fused plane-marching kernel with the
- * tile-ring densities pulled, 3 = fused plane-marching kernel with the tile-ring densities handed over from
- * the previous step (csrc/bflbm_handover.h; zero noise, lattices of full 64 x 4 tiles -- otherwise it resolves
- * to 1 or 0), 2 = auto (default): at zero noise 3 where it applies, else 1; 0 when thermal noise is on.
- * Schedules 0 and 1 give identical doubles (= the CPU reference's operation order).  Schedule 3 sums the 19
- * populations of a tile-ring density in another fixed order: deterministic, within 1 ulp of rho,phi per step
- * at the tile-edge sites' neighbours, inside the 1e-12 bar on densities/velocities, not bit-identical.
- * BFLBM_AUTO_EXACT=1 in the environment makes auto never pick 3. */
+/* Kernel schedule (what one LBM_timestep, LBM_binary.H:545-594, is run as):
+ *   0  two-pass (density pass + collide pass); bit-exact; the only one that takes injected or reference-state noise
+ *   1  fused plane-marching kernel, tile-ring densities pulled; bit-exact; zero noise or generated noise
+ *   3  pipelined plane-marching kernel, tile-ring densities handed over from the previous step
+ *      (csrc/bflbm_handover.h); zero noise or generated thermal noise (it draws the normals itself); needs a lattice
+ *      of full 64 x 4 tiles with at least two tiles per direction and no injected noise, otherwise it resolves to the
+ *      bit-exact schedule (1 at zero noise, 0 with noise).  Fails if its frames (5.6 % of the state) cannot be allocated.
+ *   2  auto (default): 3 where it applies AND alpha0 (|rho_hi| + |rho_lo|) <= 6 AND the frames fit in device memory,
+ *      else the bit-exact schedule.  BFLBM_AUTO_EXACT=1 in the environment keeps auto bit-exact, with and without noise.
+ * Schedules 0 and 1 give the CPU reference's doubles (same operation order).  Schedule 3 adds the 19 populations of
+ * a tile-ring density in another fixed order: deterministic, run-to-run reproducible, the first step after an init or
+ * upload bit-identical, later steps different from the reference by what a one-ulp change of the state does.  Measured
+ * against the CPU oracle case by case (tools/ho_stress.py, tests/test_gpu_handover_oracle.py) that equals the oracle's
+ * own response to a one-ulp perturbation: inside north_star's tolerance (rho, phi, rho+phi 1e-12 relative, velocities
+ * 1e-12 cs absolute) for every stable run, and unbounded where the reference run itself diverges (interaction strength
+ * alpha0 (rho_hi + rho_lo) >= 7.5: NaN on the CPU path within tens of steps) -- hence the parameter bound in auto. */
 int bflbm_set_schedule(bflbm_ctx* c, int schedule);
 /* The schedule (0, 1 or 3) the next step of this context will run with its current parameters and lattice. */
 int bflbm_resolved_schedule(const bflbm_ctx* c, int* schedule);
@@ -124,6 +132,10 @@ int bflbm_download_fg(bflbm_ctx* c, double* f, double* g, const bflbm_fab* box);
  * nsteps == 1 is accepted there; python/ C++ drivers wrap this. */
 int bflbm_step(bflbm_ctx* c, int nsteps);
 int bflbm_step_count(const bflbm_ctx* c, long long* steps_done);
+/* The step counter is also the noise index of the counter-based generator (one fresh set of 33 normals per site and
+ * index).  A run continued from a kBT > 0 checkpoint (main_run_job.cpp:80 step_continue, :253-270) sets it to the
+ * checkpoint's absolute step after bflbm_commit_upload(c, 1), so that it does not replay the first segment's normals. */
+int bflbm_set_step_count(bflbm_ctx* c, long long steps_done);
 
 /* One step of a slab (nranks > 1) split so that the +-z exchange overlaps the
  * interior planes.  Precondition: the resident state has valid halo planes.
@@ -168,6 +180,7 @@ int bflbm_ring_init_stripe(bflbm_ring* r, double frac);
 int bflbm_ring_init_droplet(bflbm_ring* r, double radius);
 /* after bflbm_upload_fg on every slab: exchange the uploaded faces, commit, exchange the state faces */
 int bflbm_ring_commit_upload(bflbm_ring* r, int reset_step_counter);
+int bflbm_ring_set_step_count(bflbm_ring* r, long long steps_done);   /* see bflbm_set_step_count */
 int bflbm_ring_step(bflbm_ring* r, int nsteps);            /* LBM_timestep x nsteps on the whole lattice */
 int bflbm_ring_com_sums(bflbm_ring* r, double sums[4]);    /* update_com sums over all slabs */
 int bflbm_ring_mass(bflbm_ring* r, double* rho_sum, double* phi_sum);
