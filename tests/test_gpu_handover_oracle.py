@@ -4,7 +4,8 @@ and against committed oracle trajectories, not against another GPU schedule.  LB
 
 Contract (include/bflbm.h): the first step after an init pulls its ring and equals the oracle bit for bit; later steps
 differ by a re-ordered sum of 19 numbers at tile-edge sites, which the trajectory carries forward with its own
-conditioning.  The north-star tolerances (rho, phi, rho+phi relative 1e-12; velocities absolute 1e-12 cs)
+conditioning.  The north-star tolerance 1e-12 in the metric of tests/tolerances.py (which says why a bare element-wise
+relative error is not defined for this model's near-vacuum sites)
 are asserted outright for stable runs; `test_named_stress_cases` keeps the four diverging runs of round 2's
 stress.log, where the oracle's own response to a one-ulp perturbation is the yardstick.
 """
@@ -14,6 +15,8 @@ import sys
 import numpy as np
 import pytest
 
+import tolerances
+
 pytestmark = pytest.mark.gpu
 CS = np.sqrt(1.0 / 3.0)
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
@@ -21,10 +24,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 
 def _tolerances(h, href, what=""):
-    for comp in (0, 1, 5):
-        np.testing.assert_allclose(h[comp], href[comp], rtol=1e-12, atol=0, err_msg=f"{what} comp {comp}")
-    for comp in (2, 3, 4, 6, 7, 8):
-        np.testing.assert_allclose(h[comp], href[comp], rtol=0, atol=1e-12 * CS, err_msg=f"{what} comp {comp}")
+    """tests/tolerances.py: densities to 1e-12 of the field maximum everywhere and element by element where there is
+    fluid, velocities to 1e-12 max(cs, |u|) where there is fluid, momentum to 1e-12 of its scale everywhere."""
+    return tolerances.check(h, href, what, 1e-12)
 
 
 def droplet_radius(shape):
@@ -118,11 +120,11 @@ def test_handover_with_thermal_noise_against_the_oracle(pkg, ob, threads, shape,
     """kBT > 0 (NoiseCovariance.ipynb parameters and a demixing set): the kernel draws the project's stream itself.  The
     first step equals the oracle's bit for bit -- same normals at every site and mode, same amplitudes -- and the next
     steps stay at rounding level of it (the noise is 1e-3 of the densities, the schedules differ by 1e-16)."""
-    for par in (dict(kBT=1e-5, alpha0=0.0), dict(kBT=1e-5, alpha0=1.0, tau_f=0.8)):
+    for par, init in ((dict(kBT=1e-5, alpha0=0.0), ("mixture",)), (dict(kBT=1e-5, alpha0=1.0, tau_f=0.8), ("droplet", droplet_radius(shape)))):
         ref = ob.OracleLattice(*shape, params=ob.default_params(**par))
-        ref.init_mixture()
+        getattr(ref, "init_" + init[0])(*init[1:])
         lbm = _make(pkg, shape, par, nslabs)
-        lbm.LBM_init_mixture()
+        getattr(lbm, "LBM_init_" + init[0])(*init[1:])
         ref.timestep(); lbm.LBM_timestep(1)
         f, g = lbm.populations()
         assert np.array_equal(f, ref.f) and np.array_equal(g, ref.g), (shape, par)
@@ -132,10 +134,11 @@ def test_handover_with_thermal_noise_against_the_oracle(pkg, ob, threads, shape,
             ref.timestep()
         lbm.LBM_timestep(11)
         f, g = lbm.populations()
-        assert not np.array_equal(f, ref.f) or shape[2] < 8
+        # (a uniform mixture at alpha0 = 0 has no force, so the ring densities do not enter: bit-equal throughout)
+        assert (not np.array_equal(f, ref.f)) == (init[0] == "droplet"), (shape, par)
         assert max(np.abs(f - ref.f).max(), np.abs(g - ref.g).max()) < 1e-13
         _tolerances(lbm.LBM_hydrovars(), ref.h, f"{shape} {par}")
-        assert np.abs(f - f.mean(axis=(1, 2, 3), keepdims=True)).max() > 1e-6
+        assert np.abs(fn).max() > 1e-4
         lbm.close()
 
 
@@ -222,8 +225,8 @@ def test_named_stress_cases(pkg, ob, threads, shape, frac, steps, par):
             break
         hp = ho_stress.oracle_run(shape, init, par, n, perturb=True)[0]
         hh = ho_stress.gpu_run(pkg, shape, init, par, n, "handover")[0]
-        e_ho, e_k = ho_stress.field_errors(hh, ho), ho_stress.field_errors(hp, ho)
-        assert max(e_ho) <= max(1e-12, 10 * max(e_k)), (n, e_ho, e_k)
+        e_ho, e_k = max(tolerances.errors(hh, ho).values()), max(tolerances.errors(hp, ho).values())
+        assert e_ho <= max(1e-12, 10 * e_k), (n, e_ho, e_k)
     _against_oracle(pkg, ob, shape, init, {}, 1, checkpoints=(1, steps))            # (c)
 
 
