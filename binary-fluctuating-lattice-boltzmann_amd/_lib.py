@@ -71,6 +71,7 @@ SIGNATURES = {
     "bflbm_halo_bytes": (ctypes.c_int, [_vp, ctypes.c_int, _P(ctypes.c_size_t)]),
     "bflbm_halo_pack": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     "bflbm_halo_unpack": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "bflbm_halo_planes": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P(_vp), _P(ctypes.c_size_t), _P(ctypes.c_int)]),
     "bflbm_ring_create": (ctypes.c_int, [_P(Params), _P(ctypes.c_int), ctypes.c_int, _P(ctypes.c_int), ctypes.c_int, _P(_vp)]),
     "bflbm_ring_destroy": (ctypes.c_int, [_vp]),
     "bflbm_ring_size": (ctypes.c_int, [_vp, _P(ctypes.c_int)]),

@@ -222,10 +222,28 @@ inline bool handover_contract_params(const bflbm_params& p) {
   return std::fabs(p.alpha0) * (std::fabs(p.rho_hi) + std::fabs(p.rho_lo)) <= 6.0;
 }
 
+// Where `auto` expects schedule 3 to be the faster one (A/B on MI355X, tools/ragged_ab.sh):
+// it needs marches of at least 16 planes per workgroup (64^3: 16 tile columns cut into chunks of 4 planes, of whose 6
+// positions only 2 read frames: -13 %; 64 x 64 x 256 and 128 x 128 x 64, chunks of 16: equal or better), and at zero
+// noise, where the alternative is the one-pass schedule 1, whole tile rows (a lower last row puts three tile rows on the
+// pulled ring: 250^3 -3 %, 256 x 250 x 256 -2 %) and a last tile column that is not mostly idle lanes (96^3: 75 % of
+// the lanes busy, -9 %; 200^3: 78 %, +4 %; 300^3: +11 ... 18 %).  With noise the alternative is the two-pass schedule
+// and the hand-over kernel wins on every ragged lattice measured (250^3 +18 %).  BFLBM_AUTO_MIN_LZ overrides the 16.
+inline bool handover_worthwhile(const bflbm_ctx* c, bool noisy) {
+  static const int min_lz = [] { const char* e = getenv("BFLBM_AUTO_MIN_LZ"); return e ? atoi(e) : 16; }();
+  const int lo = c->G.H, hi = c->G.H + c->nzl;
+  FusedGrid F;
+  handover_plan(c->G, c->G.zwrap ? lo : lo + 2, c->G.zwrap ? hi : hi - 2, 0, F);
+  if (F.lz < min_lz) return false;
+  if (noisy) return true;
+  const double lanes_busy = (double)c->G.nx / (64.0 * F.ntx);
+  return c->G.ny % BFLBM_HO_TY == 0 && lanes_busy >= 0.77;
+}
+
 // 0 two-pass, 1 fused (pulled ring), 3 hand-over.  The bit-exact choice is 1 at zero noise and 0 with noise.
 // auto (2): the pipelined hand-over kernel wherever the lattice has full 64 x 4 tiles with distinct neighbours (it
-// generates thermal noise itself but takes no injected noise), the parameters are inside the range above and the
-// frames fit in memory; BFLBM_AUTO_EXACT=1 keeps auto on the bit-exact schedules with and without noise.
+// generates thermal noise itself but takes no injected noise) where it is the faster one, the parameters are inside the
+// range above and the frames fit in memory; BFLBM_AUTO_EXACT=1 keeps auto on the bit-exact schedules with and without noise.
 inline int resolved_schedule(const bflbm_ctx* c) {
   if (ref_active(c)) return 0;                   // needs the densities and their centre of mass first
   const bool noisy = c->dp.noise_on || c->inject;
@@ -235,6 +253,7 @@ inline int resolved_schedule(const bflbm_ctx* c) {
   static const int auto_noise_fused = [] { const char* e = getenv("BFLBM_AUTO_NOISE_HANDOVER"); return e ? atoi(e) != 0 : true; }();
   static const int auto_exact = [] { const char* e = getenv("BFLBM_AUTO_EXACT"); return e && atoi(e) != 0; }();
   if (auto_exact || c->inject || c->frames_unavailable || !handover_ok(c->G) || !handover_contract_params(c->prm)) return exact;
+  if (!handover_worthwhile(c, noisy)) return exact;
   if (noisy && !auto_noise_fused) return 0;
   return 3;
 }
@@ -716,6 +735,22 @@ int bflbm_halo_unpack(bflbm_ctx* c, int kind, int side, const void* buf) {
   return 0;
 }
 
+// Staging-free exchange for a driver that owns the transport (RCCL P2P in slab.SlabLattice): every entry of the halo
+// table is ONE contiguous component plane of the state buffer, so a sender can post it straight from where the boundary
+// kernels wrote it and a receiver straight into the halo plane the next step pulls from.
+int bflbm_halo_planes(bflbm_ctx* c, int kind, int side, int pack, void** planes, size_t* plane_bytes, int* count) {
+  if (!c || !planes || !plane_bytes || !count) return fail("null argument");
+  if (c->G.zwrap) return fail("halo exchange on a single slab");
+  if (kind < 0 || kind > 2 || side < 0 || side > 1) return fail("bad halo kind/side");
+  HaloTable T; halo_table(c, kind, side, pack != 0, T);
+  double* base = halo_buffer(c, kind);
+  for (int e = 0; e < 2 * Q; ++e) planes[e] = base + (size_t)T.comp[e] * (size_t)c->G.vol + (size_t)T.plane[e] * (size_t)c->G.plane;
+  *plane_bytes = (size_t)c->G.plane * sizeof(double);
+  *count = 2 * Q;
+  if (!pack && kind == BFLBM_HALO_STATE) c->density_valid = false;    // the caller is about to overwrite halo planes of the resident state
+  return 0;
+}
+
 // ---- observables -----------------------------------------------------------------------
 static int observe(bflbm_ctx* c, int what, int ncomp_out, double* dst, double* dst2, int ncomp_host, const bflbm_fab* box) {
   if (c->step_open) return fail("observables requested inside an open step");
@@ -960,7 +995,10 @@ static int ring_copy(bflbm_ring* r, int kind) {
       double* dst_base = halo_buffer(c, kind);
       const double* src_base = halo_buffer(src, kind);
       for (int e = 0; e < 2 * Q; ++e) if (Tu.comp[e] != Tp.comp[e]) return fail("halo tables of neighbouring slabs disagree");
-      const bool reachable = (src->dom.device == c->dom.device) || r->peer_ok[k][side];
+      // BFLBM_RING_COPY_FALLBACK=1 forces the per-plane copies (what a pair of GPUs without peer mapping gets), so that
+      // both branches are exercised on a one-GPU box (tests/test_gpu_slabs.py)
+      static const bool force_copies = [] { const char* e = getenv("BFLBM_RING_COPY_FALLBACK"); return e && atoi(e) != 0; }();
+      const bool reachable = !force_copies && ((src->dom.device == c->dom.device) || r->peer_ok[k][side]);
       if (reachable && (c->G.plane % 2 == 0) && (c->G.vol % 2 == 0) && (src->G.vol % 2 == 0)) {
         // one gather kernel per face reads the neighbour's planes in place (peer memory over xGMI between GPUs)
         dim3 g((unsigned)((c->G.plane / 2 + 255) / 256), (unsigned)(2 * Q));
@@ -1021,7 +1059,7 @@ int bflbm_ring_create(const bflbm_params* p, const int n[3], int nslabs, const i
       if (e == hipSuccess) e = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&e2, hipEventDisableTiming);
       r->comm.push_back(st); r->packed.push_back(e1); r->unpacked.push_back(e2);
-      // peer access to the ring neighbours' send buffers (a no-op when they share the device)
+      // peer mapping of the ring neighbours' state buffers, which k_halo_pull reads in place (nothing to do when they share the device)
       std::array<bool, 2> ok = {false, false};
       const int nbs[2] = { (k + nslabs - 1) % nslabs, (k + 1) % nslabs };       // lower, upper
       for (int sd = 0; sd < 2; ++sd) {

@@ -33,6 +33,7 @@ struct FusedGrid {
   int total;           // ncols*nchunks workgroups
   int per_xcd;         // ceil(total/8)
   int sx;              // strip width (tiles in x) of the column order, see fused_map
+  int row0 = 0;        // the column order starts at this tile row (hand-over kernel on a lattice with a lower last tile row)
 };
 
 // Workgroup -> (column, chunk).  Workgroups b and b+8 share an XCD (round-robin dispatch), so give

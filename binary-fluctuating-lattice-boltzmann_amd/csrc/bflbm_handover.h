@@ -27,8 +27,18 @@
 // bit-exact schedules (0 two-pass, 1 fused with pulled ring) remain the cross-check.
 //
 // Frames of the first and last plane of a chunk would need sources of the neighbouring chunk: those planes
-// (and every plane of the first step after an init/upload) use the pulled ring.  Requires full tiles
-// (nx % 64 == 0, ny % TY == 0) and at least two tiles per direction; the host falls back to schedule 1 otherwise.
+// (and every plane of the first step after an init/upload) use the pulled ring.
+//
+// Lattices that are not whole tiles (template flag RAG; the full-tile kernel is compiled without any of it):
+//   x  the last tile of a row may be narrower (aw < 64 sites): its idle lanes load a duplicate of the last site, store
+//      nothing and contribute zeros to the x shifts; its right column lane is aw-1 and its right ring column aw+1, and
+//      the frames keep their layout (slots are roles, not coordinates), so a narrow tile hands over like any other.
+//   y  the last tile row may be lower (ah < TY rows).  The y roles of the producer need TY >= 4 distinct rows, so that
+//      tile row produces no frames and pulls its ring, and the two tile rows next to it (above, periodically, and below)
+//      pull theirs too while still producing: three tile rows out of ny/TY on the pulled ring, the rest unchanged.
+// A ring site is looked up by its coordinates RELATIVE to each of the 3 x 3 surrounding tiles (not by wrapped global
+// coordinates), so a lattice one tile wide or high -- where the neighbour on both sides is the tile itself and a ring
+// site is one of its own edge sites at the same time -- needs nothing special: nx >= 64 (one tile: nx = 64), ny >= TY.
 #ifndef BFLBM_HANDOVER_H_
 #define BFLBM_HANDOVER_H_
 
@@ -53,9 +63,8 @@ struct HoGrid {
 
 // destination slot of lattice site (lx,ly), given relative to a tile's origin, in that tile's frame; -1: none
 template <int TY>
-__device__ __forceinline__ int ho_frame_slot(int lx, int ly) {
+__device__ __forceinline__ int ho_frame_slot(int lx, int ly, int TX /* width of the tile that owns the frame */) {
   using L = HoLayout<TY>;
-  constexpr int TX = L::TX;
   if (lx >= 0 && lx < TX && ly >= 0 && ly < TY) {
     if (ly == 0) return L::EB + lx;
     if (ly == TY - 1) return L::ET + lx;
@@ -74,15 +83,6 @@ __device__ __forceinline__ int ho_frame_slot(int lx, int ly) {
   }
   return -1;
 }
-// coordinate g relative to origin o on a periodic axis of length n, mapped to [-1, T] or a large value
-__device__ __forceinline__ int ho_rel(int g, int o, int n, int T) {
-  int d = g - o;
-  if (d < 0) d += n;
-  if (d <= T) return d;
-  if (d == n - 1) return -1;
-  return 1 << 20;
-}
-
 __device__ __forceinline__ double ho_shr(double v) {   // value of lane-1 (travelling +x), 0 in lane 0
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
@@ -103,7 +103,8 @@ __device__ __forceinline__ double ho_shl(double v) {   // value of lane+1 (trave
 // form, and the variants that kept the f plane in registers or requested the next plane before the density sums,
 // were measured and removed: DESIGN.md section 3.1b.)
 // MODE 0: zero noise; MODE 1: generated thermal noise (csrc/bflbm_rng.h), drawn where it is added.
-template <int TY, int MODE>
+// RAG: the lattice has a narrower last tile column and/or a lower last tile row (see the header comment)
+template <int TY, int MODE, bool RAG>
 __global__ void __launch_bounds__(64 * TY, 1)
 k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParams P, FusedGrid F, HoGrid Hg, uint32_t noise_index) {
   using L = HoLayout<TY>;
@@ -124,7 +125,9 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   int col, chunk;
   if (!fused_map(F, (int)blockIdx.x, col, chunk)) return;   // whole workgroup leaves together
   if (MODE == 1) d_load_normal_table(ntab, true);
-  const int tix = col % F.ntx, tiy = col / F.ntx;
+  const int tix = col % F.ntx;
+  int tiy = col / F.ntx + F.row0;
+  if (tiy >= F.nty) tiy -= F.nty;
   const int x0 = tix * TX, y0 = tiy * TY;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -135,7 +138,18 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   auto ld = [](const double* __restrict__ base, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff); };
   auto st = [](double* __restrict__ base, unsigned boff, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v; };
 
-  const int x = x0 + tx, y = y0 + ty;
+  // active extent of this tile; idle lanes / rows of a ragged tile work on a duplicate of the last active site
+  const int aw = RAG ? min(TX, G.nx - x0) : TX, ah = RAG ? min(TY, G.ny - y0) : TY;
+  const bool active_x = !RAG || tx < aw;
+  const bool active = !RAG || (tx < aw && ty < ah);
+  const int x = x0 + (RAG ? min(tx, aw - 1) : tx), y = y0 + (RAG ? min(ty, ah - 1) : ty);
+  // frames: produced unless this is the lower last tile row; consumed unless that row is this one or a y neighbour
+  bool produce = true, consume = true;
+  if (RAG && G.ny % TY != 0) {
+    const int last = F.nty - 1, up = tiy == last ? 0 : tiy + 1, dn = tiy == 0 ? last : tiy - 1;
+    produce = tiy != last;
+    consume = produce && up != last && dn != last;
+  }
   const unsigned xo[3] = { (unsigned)wrapx(x - 1) * 8u, (unsigned)x * 8u, (unsigned)wrapx(x + 1) * 8u };
   const unsigned yo[3] = { (unsigned)(wrapy(y - 1) * G.pitch) * 8u, (unsigned)(y * G.pitch) * 8u, (unsigned)(wrapy(y + 1) * G.pitch) * 8u };
   const int lown = (ty + 1) * LW + (tx + 1);
@@ -146,7 +160,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   const bool edge_row = (ty == 0) || (ty == TY - 1);
   const bool is_edge = (tid < TX) || (tid >= NT - TX);       // the same as a lane predicate (keeps the producer free of uniform branches)
   const int side_y = row_down ? 0 : 1;
-  const bool col_lane = (tx == 0) || (tx == TX - 1);
+  const bool col_lane = (tx == 0) || (tx == aw - 1);         // aw >= 2 (host check)
   const int side_x = (tx == 0) ? 0 : 1;
   const unsigned tile_rec = (unsigned)((tiy * F.ntx + tix) * L::REC) * 8u;     // byte offset of this tile's frame in a plane
   // ---- ring site of this thread when the ring comes from frames, both fluids.  Wave 0 takes the 64 sites below
@@ -154,27 +168,31 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   // 512-byte frame rows, four full lines per load.  The 4 corners and 2*TY column sites, which have up to four
   // pieces in scattered places, go to lanes of wave 2.  (Spread evenly over the four waves, every wave issued all
   // eight frame loads on parts of those rows: twice the instructions and half again the line requests.)
-  const bool has_rtask = ty < 2 || (ty == 2 && lane < 4 + 2 * TY);
+  const bool has_rtask = (ty < 2 && lane < aw) || (ty == 2 && lane < 4 + 2 * TY);
   int hlx = 0, hly = 0;
   if (ty == 0) { hlx = lane + 1; hly = 0; }
   else if (ty == 1) { hlx = lane + 1; hly = TY + 1; }
-  else if (ty == 2 && lane < 4) { hlx = (lane & 1) ? TX + 1 : 0; hly = (lane & 2) ? TY + 1 : 0; }
+  else if (ty == 2 && lane < 4) { hlx = (lane & 1) ? aw + 1 : 0; hly = (lane & 2) ? TY + 1 : 0; }
   else if (ty == 2 && lane < 4 + TY) { hlx = 0; hly = lane - 4 + 1; }
-  else if (ty == 2 && lane < 4 + 2 * TY) { hlx = TX + 1; hly = lane - 4 - TY + 1; }
+  else if (ty == 2 && lane < 4 + 2 * TY) { hlx = aw + 1; hly = lane - 4 - TY + 1; }
   const int lhalo = hly * LW + hlx;
-  // the frames that hold a piece of this ring site: the owner's E and the O of every other tile around it
+  // the frames that hold a piece of this ring site: the owner's E and the O of every other tile around it.  The site
+  // is (hlx-1, hly-1) in this tile's coordinates, hence (that - offset of the tile) in the coordinates of each of the
+  // 3 x 3 tiles around; when two of those are the same tile (one or two tiles per direction) they are different
+  // REPRESENTATIONS of the site in that tile's frame, and at most one of them names a slot per piece.
   unsigned fo[4] = {0u, 0u, 0u, 0u};
   int nfo = 0;
-  if (has_rtask) {
-    const int gx = wrapx(x0 + hlx - 1), gy = wrapy(y0 + hly - 1);
+  if (has_rtask && consume) {
+    const int wlast = G.nx - (F.ntx - 1) * TX;               // width of the last tile column (TX when full)
     for (int dty = -1; dty <= 1; ++dty) {
-      if (dty == 1 && F.nty == 2) continue;                  // the same tile as dty = -1
       for (int dtx = -1; dtx <= 1; ++dtx) {
-        if (dtx == 1 && F.ntx == 2) continue;
         int ux = tix + dtx, uy = tiy + dty;
         ux = ux < 0 ? ux + F.ntx : (ux >= F.ntx ? ux - F.ntx : ux);
         uy = uy < 0 ? uy + F.nty : (uy >= F.nty ? uy - F.nty : uy);
-        const int slot = ho_frame_slot<TY>(ho_rel(gx, ux * TX, G.nx, TX), ho_rel(gy, uy * TY, G.ny, TY));
+        const int wu = (ux == F.ntx - 1) ? wlast : TX;
+        const int lx = (hlx - 1) + (dtx < 0 ? wu : (dtx > 0 ? -aw : 0));
+        const int ly = (hly - 1) - dty * TY;
+        const int slot = ho_frame_slot<TY>(lx, ly, wu);
         if (slot >= 0 && nfo < 4) { fo[nfo] = (unsigned)((uy * F.ntx + ux) * L::REC + slot) * 8u; ++nfo; }
       }
     }
@@ -194,7 +212,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
 
   // finish the frames of plane tpf from what the previous march position left in LDS (after a barrier)
   auto finish = [&](int tpf, int rb) {
-    if (tpf < fa || tpf > fb) return;
+    if (tpf < fa || tpf > fb || !produce) return;
     double* __restrict__ fp = Hg.fout + (long long)tpf * Hg.fplane;
     if (edge_row) {
 #pragma unroll
@@ -238,7 +256,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       if (which != 2) f[i] = ld(b, o);
       if (which != 1) g[i] = ld(b + (long long)Q * G.vol, o);
     }
-    if (which != 2 && Hg.use_frames && q >= fa && q <= fb && has_rtask) {
+    if (which != 2 && Hg.use_frames && consume && q >= fa && q <= fb && has_rtask) {
       const double* __restrict__ fp = Hg.fin + (long long)q * Hg.fplane;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -273,7 +291,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     for (int i = 0; i < Q; ++i) { cf[i] = nf[i]; cg[i] = ng[i]; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { hv[0][j] = hvn[0][j]; hv[1][j] = hvn[1][j]; }
-    const bool ring_from_frames = Hg.use_frames && q >= fa && q <= fb;       // uniform over the workgroup
+    const bool ring_from_frames = Hg.use_frames && consume && q >= fa && q <= fb;       // uniform over the workgroup
     double zero = 0.0;
     asm volatile("" : "+v"(zero));
     auto density = [&](const double (&fs)[Q]) { double r = zero;
@@ -281,7 +299,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       for (int i = 0; i < Q; ++i) r += fs[i];
       return r; };
     if (ring_from_frames) {
-      rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg);
+      if (active) { rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg); }
       if (has_rtask) {
         double r0 = hv[0][0] + hv[0][1], r1 = hv[1][0] + hv[1][1];
         if (nfo > 2) { r0 += hv[0][2]; r1 += hv[1][2]; }
@@ -289,16 +307,17 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
         rp[slot][0][lhalo] = r0; rp[slot][1][lhalo] = r1;
       }
     } else {
-      rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg);
-      // pulled ring (chunk-boundary planes, first step): threads 0..NRING-1 pull one ring site, both fluids in one
-      // batch of 38 loads (wave-uniform base + 32-bit lane offset, like the own loads); a rare path
-      if (tid < NRING) {
+      if (active) { rp[slot][0][lown] = density(cf); rp[slot][1][lown] = density(cg); }
+      // pulled ring (chunk-boundary planes, first step, tile rows next to a lower last row): threads 0..nring-1 pull
+      // one ring site, both fluids in one batch of 38 loads (wave-uniform base + 32-bit lane offset, like the own
+      // loads); a rare path
+      if (tid < (RAG ? 2 * (aw + 2) + 2 * ah : NRING)) {
         const int r = tid;
         int rx, ry;
-        if (r < TX + 2) { rx = r; ry = 0; }
-        else if (r < 2 * (TX + 2)) { rx = r - (TX + 2); ry = TY + 1; }
-        else if (r < 2 * (TX + 2) + TY) { rx = 0; ry = r - 2 * (TX + 2) + 1; }
-        else { rx = TX + 1; ry = r - 2 * (TX + 2) - TY + 1; }
+        if (r < aw + 2) { rx = r; ry = 0; }
+        else if (r < 2 * (aw + 2)) { rx = r - (aw + 2); ry = ah + 1; }
+        else if (r < 2 * (aw + 2) + ah) { rx = 0; ry = r - 2 * (aw + 2) + 1; }
+        else { rx = aw + 1; ry = r - 2 * (aw + 2) - ah + 1; }
         const int hx = wrapx(x0 + rx - 1), hy = wrapy(y0 + ry - 1);
         const unsigned hxo[3] = { (unsigned)wrapx(hx - 1) * 8u, (unsigned)hx * 8u, (unsigned)wrapx(hx + 1) * 8u };
         const unsigned hyo[3] = { (unsigned)(wrapy(hy - 1) * G.pitch) * 8u, (unsigned)(hy * G.pitch) * 8u, (unsigned)(wrapy(hy + 1) * G.pitch) * 8u };
@@ -376,7 +395,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       double v_b[3];
       d_barycentric(r, ph, Hy, v_b, R);
       const int tp = pc - 1;                                   // plane whose sums become complete now
-      const bool tp_ok = tp >= fa && tp <= fb;
+      const bool tp_ok = produce && tp >= fa && tp <= fb;
       double* __restrict__ fp = Hg.fout + (long long)tp * Hg.fplane;
       const int wb = it & 1;
       const double zn[Q] = {0.};
@@ -387,25 +406,28 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
         PopTerms T;
         d_population_terms(mom, T);
         double* __restrict__ Dk = Dp + (long long)(k * Q) * G.vol;
-        auto put = [&](int i, double v) { st(Dk + (long long)i * G.vol, os3[1 + BFLBM_SX(Vel::cx[i])], v); };
+        auto put = [&](int i, double v) { if (active) st(Dk + (long long)i * G.vol, os3[1 + BFLBM_SX(Vel::cx[i])], v); };
+        // x shifts see zeros from the idle lanes of a narrow tile (they hold a duplicate of the last site)
+        auto shr = [&](double v) { return ho_shr((RAG && !active_x) ? 0.0 : v); };
+        auto shl = [&](double v) { return ho_shl((RAG && !active_x) ? 0.0 : v); };
         auto diag = [&](int g, int j) {          // population j of plane g (d_populations)
           return j == 0 ? T.B[g] + T.p[g] + T.q[g] + T.r[g] : j == 1 ? T.B[g] - T.p[g] - T.q[g] + T.r[g]
                : j == 2 ? T.B[g] + T.p[g] - T.q[g] - T.r[g] : T.B[g] - T.p[g] + T.q[g] - T.r[g]; };
         const double o0 = T.rest, o1 = T.E[0] + T.O[0], o2 = T.E[0] - T.O[0];
         put(0, o0); put(1, o1); put(2, o2);
-        const double x00 = o0 + ho_shr(o1) + ho_shl(o2);
+        const double x00 = o0 + shr(o1) + shl(o2);
         const double o3 = T.E[1] + T.O[1], o7 = diag(0, 0), o10 = diag(0, 3);
         put(3, o3); put(7, o7); put(10, o10);
-        const double xp0 = o3 + ho_shr(o7) + ho_shl(o10);
+        const double xp0 = o3 + shr(o7) + shl(o10);
         const double o4 = T.E[1] - T.O[1], o9 = diag(0, 2), o8 = diag(0, 1);
         put(4, o4); put(9, o9); put(8, o8);
-        const double xm0 = o4 + ho_shr(o9) + ho_shl(o8);
+        const double xm0 = o4 + shr(o9) + shl(o8);
         const double o5 = T.E[2] + T.O[2], o15 = diag(2, 0), o18 = diag(2, 2);
         put(5, o5); put(15, o15); put(18, o18);
-        const double x0p = o5 + ho_shr(o15) + ho_shl(o18);
+        const double x0p = o5 + shr(o15) + shl(o18);
         const double o6 = T.E[2] - T.O[2], o17 = diag(2, 3), o16 = diag(2, 1);
         put(6, o6); put(17, o17); put(16, o16);
-        const double x0m = o6 + ho_shr(o17) + ho_shl(o16);
+        const double x0m = o6 + shr(o17) + shl(o16);
         const double o11 = diag(1, 0), o12 = diag(1, 1), o13 = diag(1, 2), o14 = diag(1, 3);
         put(11, o11); put(12, o12); put(13, o13); put(14, o14);
         // what leaves the tile in x (column lanes only; side_x picks the lane's outward direction)
@@ -469,32 +491,38 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
 #define BFLBM_HO_TY 4
 #endif
 
-// hand-over frames need full tiles and distinct neighbour tiles
+// lattices the hand-over kernel takes: at least one whole tile; a narrower last tile column needs two lanes (its left
+// and right column roles must be different lanes)
 static inline bool handover_ok(const Geo& G) {
   constexpr int TY = BFLBM_HO_TY;
-  return (G.nx % 64 == 0) && (G.ny % TY == 0) && (G.nx / 64 >= 2) && (G.ny / TY >= 2);
+  return G.nx >= 64 && (G.nx % 64 == 0 || G.nx % 64 >= 2) && G.ny >= TY;
 }
+static inline bool handover_ragged(const Geo& G) { return G.nx % 64 != 0 || G.ny % BFLBM_HO_TY != 0; }
 static inline size_t handover_frame_doubles(const Geo& G) {
   constexpr int TY = BFLBM_HO_TY;
-  return (size_t)(G.nx / 64) * (size_t)(G.ny / TY) * HoLayout<TY>::REC * (size_t)G.nzs;
+  return (size_t)((G.nx + 63) / 64) * (size_t)((G.ny + TY - 1) / TY) * HoLayout<TY>::REC * (size_t)G.nzs;
 }
 
 struct HoSig { int pa = -1, pb = -1, lz = -1, nchunks = -1, cstride = -1; long long step = -1;
   bool same_geometry(const HoSig& o) const { return pa == o.pa && pb == o.pb && lz == o.lz && nchunks == o.nchunks && cstride == o.cstride; } };
 
-// fin/fout: frame buffers of the state read / written.  sig_in: what wrote fin (step == steps-1 required);
-// sig_out receives this launch.  returns non-zero on launch failure
-static inline int handover_launch(const double* S, double* D, const double* fin, double* fout, const Geo& G, const DevParams& P,
-                                  int pa, int pb, long long steps, const HoSig& sig_in, HoSig& sig_out, hipStream_t stream, int pair_len = 0, int mode = 0) {
+// Chunking and workgroup order of one launch over the storage planes [pa, pb) (pair_len > 0: the two boundary plane
+// pairs of a slab, one chunk each).  One workgroup is resident per CU, so a launch runs in rounds of `slots` workgroups
+// and costs about rounds x (planes per chunk + 1) march positions; the chunk count minimises that.
+static inline void handover_plan(const Geo& G, int pa, int pb, int pair_len, FusedGrid& F) {
   constexpr int TX = 64, TY = BFLBM_HO_TY;
-  FusedGrid F;
-  F.ntx = G.nx / TX; F.nty = G.ny / TY;
+  F.ntx = (G.nx + TX - 1) / TX; F.nty = (G.ny + TY - 1) / TY;
   F.ncols = F.ntx * F.nty;
   F.pa = pa; F.pb = pb;
   const int np = pb - pa;
   static const int want_env = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 0; }();
   const int slots = g_fused_ncu > 0 ? g_fused_ncu : 256;        // one workgroup per CU
   static const int min_slab_rounds = [] { const char* e = getenv("BFLBM_SLAB_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
+  // A lower last tile row puts three tile rows on the pulled ring (1.3x the time of the others, measured on the first
+  // step of every run).  In a single round those workgroups ARE the launch time (250^3: 5584 MLUPS against 6444 for
+  // schedule 1); with three rounds or more, and those rows first in the order, they overlap with the rest.
+  const bool low_row = G.ny % TY != 0;
+  F.row0 = low_row ? std::max(0, F.nty - 2) : 0;
   const int maxchunks = std::max(1, np / 4);                     // a chunk shorter than 4 planes has no complete frame
   int nchunks;
   if (want_env > 0) {
@@ -506,7 +534,7 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
       if (chunks != k) continue;
       if (G.zwrap && lz > 256 && k < maxchunks) continue;   // one 512-plane march per column was A/B-tested: -1 %
       const long long total = (long long)F.ncols * chunks, rounds = (total + slots - 1) / slots;
-      if (!G.zwrap && rounds < min_slab_rounds && k < maxchunks) continue;
+      if ((!G.zwrap || low_row) && rounds < min_slab_rounds && k < maxchunks) continue;
       const long long cost = rounds * (lz + 1);
       if (best < 0 || cost < best) { best = cost; nchunks = k; }
     }
@@ -518,6 +546,15 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
   F.total = F.ncols * F.nchunks;
   F.per_xcd = (F.total + 7) / 8;
   { static const int sx_env = [] { const char* e = getenv("BFLBM_MAP_SX"); return e ? atoi(e) : 0; }(); F.sx = sx_env > 0 ? sx_env : F.ntx; }
+}
+
+// fin/fout: frame buffers of the state read / written.  sig_in: what wrote fin (step == steps-1 required);
+// sig_out receives this launch.  returns non-zero on launch failure
+static inline int handover_launch(const double* S, double* D, const double* fin, double* fout, const Geo& G, const DevParams& P,
+                                  int pa, int pb, long long steps, const HoSig& sig_in, HoSig& sig_out, hipStream_t stream, int pair_len = 0, int mode = 0) {
+  constexpr int TX = 64, TY = BFLBM_HO_TY;
+  FusedGrid F;
+  handover_plan(G, pa, pb, pair_len, F);
   sig_out.pa = pa; sig_out.pb = pb; sig_out.lz = F.lz; sig_out.nchunks = F.nchunks; sig_out.cstride = F.cstride; sig_out.step = steps;
   HoGrid Hg;
   Hg.fin = fin; Hg.fout = fout;
@@ -525,8 +562,11 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
   Hg.use_frames = (sig_in.step == steps - 1 && sig_in.same_geometry(sig_out)) ? 1 : 0;
   dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
   const uint32_t nidx = (uint32_t)steps;
-  if (mode == 1) hipLaunchKernelGGL((k_fused_ho<TY, 1>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
-  else           hipLaunchKernelGGL((k_fused_ho<TY, 0>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
+  const bool rag = handover_ragged(G);
+  if (mode == 1) { if (rag) hipLaunchKernelGGL((k_fused_ho<TY, 1, true>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
+                   else     hipLaunchKernelGGL((k_fused_ho<TY, 1, false>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx); }
+  else           { if (rag) hipLaunchKernelGGL((k_fused_ho<TY, 0, true>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
+                   else     hipLaunchKernelGGL((k_fused_ho<TY, 0, false>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx); }
   return hipGetLastError() != hipSuccess;
 }
 

@@ -53,6 +53,13 @@ def _check_array(a, ncomp, shape3, name):
         raise ValueError(f"{name}: shape {a.shape}, expected {(ncomp,) + tuple(shape3)}")
 
 
+class _DevicePlane:
+    """A component plane of the resident state as seen by torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr, ndoubles):
+        self.__cuda_array_interface__ = {"shape": (int(ndoubles),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
 class _DropletMixin:
     """Droplet observables reduced on the device (csrc/bflbm_droplet.h); `_droplet_fn` names the C-ABI pair."""
 
@@ -321,6 +328,26 @@ class BinaryLBM(_DropletMixin):
 
     def halo_unpack(self, kind, side, device_ptr):
         check(self.lib.bflbm_halo_unpack(self._h, int(kind), int(side), ctypes.c_void_p(device_ptr)))
+
+    def halo_planes(self, kind, side, pack):
+        """(device addresses of the 38 component planes of a face, bytes per plane): the staging-free exchange."""
+        ptrs = (ctypes.c_void_p * 64)()
+        nb, cnt = ctypes.c_size_t(), ctypes.c_int()
+        check(self.lib.bflbm_halo_planes(self._h, int(kind), int(side), int(bool(pack)), ptrs, ctypes.byref(nb), ctypes.byref(cnt)))
+        return [int(ptrs[k]) for k in range(cnt.value)], nb.value
+
+    def halo_plane_tensors(self, kind, side, pack, device):
+        """The same as torch tensors that alias the state buffer (zero-copy, through __cuda_array_interface__)."""
+        import torch
+        cache = self.__dict__.setdefault("_plane_views", {})
+        ptrs, nb = self.halo_planes(kind, side, pack)
+        out = []
+        for p in ptrs:
+            t = cache.get(p)
+            if t is None:
+                t = cache[p] = torch.as_tensor(_DevicePlane(p, nb // 8), device=device)
+            out.append(t)
+        return out
 
     # -- misc ------------------------------------------------------------------------------
     def sync(self):

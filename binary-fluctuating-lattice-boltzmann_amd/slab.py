@@ -8,11 +8,19 @@ cross a z face: 38 component-planes per face (see csrc/bflbm.hip halo_table).  T
 of step t's results is posted as soon as the slab's two outermost plane pairs are done and
 overlaps the interior planes of the same step:
 
-    step_boundary -> pack -> isend/irecv (RCCL stream) || step_interior -> wait -> unpack -> finish
+    step_boundary -> 38 isend + 38 irecv per face, one batch (RCCL stream) || step_interior -> wait -> finish
+
+Every (component, plane) entry of a face is one contiguous plane of the state buffer, so the sends are posted straight
+from the planes the boundary kernels wrote and the receives straight into the halo planes the next step pulls from
+(`halo_plane_tensors`): no pack/unpack kernels, no buffers.  With two ranks both faces go to the same peer in that one
+batch.  An engine without `halo_plane_tensors`, or BFLBM_SLAB_STAGED=1, takes the staged path (pack -> one message per
+face -> unpack) instead.
 
 torch.distributed is plumbing only (process group, P2P); all lattice work is in the HIP library.
 `engine_factory` lets the CPU test-suite drive the same protocol with a stand-in engine.
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -93,7 +101,8 @@ class SlabLattice(_Protocol):
         # RCCL orders its work after the current stream by itself; host-driven backends (gloo) read
         # the send buffers from the host side, so the pack kernels must have completed first.
         self._host_sync = dist.get_backend(group) != "nccl"
-        if self.world > 1:
+        self.direct = hasattr(engine, "halo_plane_tensors") and os.environ.get("BFLBM_SLAB_STAGED", "0") != "1"
+        if self.world > 1 and not self.direct:
             n = engine.halo_bytes(_lib.HALO_STATE) // 8
             mk = lambda: torch.empty(n, dtype=torch.float64, device=self.device)
             # send_lo goes to the lower neighbour (its high halo); recv_hi comes from the upper one
@@ -105,6 +114,8 @@ class SlabLattice(_Protocol):
     def _post(self, kind):
         if self.world == 1:
             return
+        if self.direct:
+            return self._post_direct(kind)
         e, b, dist = self.engine, self._bufs, self.dist
         e.halo_pack(kind, 0, b["send_lo"].data_ptr())
         e.halo_pack(kind, 1, b["send_hi"].data_ptr())
@@ -119,12 +130,32 @@ class SlabLattice(_Protocol):
                dist.P2POp(dist.irecv, b["recv_lo"], lo, self.group, tag=1)]
         self._work = dist.batch_isend_irecv(ops)
 
+    def _post_direct(self, kind):
+        """One batch of plane-sized P2P operations between the state buffers themselves.  Entry k of my low face pairs
+        with entry k of the lower neighbour's high halo (same table order on both sides); the tag carries face and
+        entry so that host-driven backends match them too.  Posting order as in the staged path: with two ranks the
+        peer's first receives (its high halo, from ITS upper neighbour = me) meet my first sends (my low face)."""
+        e, dist = self.engine, self.dist
+        dev = self.device
+        s_lo, s_hi = e.halo_plane_tensors(kind, 0, True, dev), e.halo_plane_tensors(kind, 1, True, dev)
+        r_lo, r_hi = e.halo_plane_tensors(kind, 0, False, dev), e.halo_plane_tensors(kind, 1, False, dev)
+        if self._host_sync:
+            e.sync()
+        lo, up = self._ranks(self.lower), self._ranks(self.upper)
+        ops = [dist.P2POp(dist.isend, t, lo, self.group, tag=k) for k, t in enumerate(s_lo)]
+        ops += [dist.P2POp(dist.isend, t, up, self.group, tag=64 + k) for k, t in enumerate(s_hi)]
+        ops += [dist.P2POp(dist.irecv, t, up, self.group, tag=k) for k, t in enumerate(r_hi)]
+        ops += [dist.P2POp(dist.irecv, t, lo, self.group, tag=64 + k) for k, t in enumerate(r_lo)]
+        self._work = dist.batch_isend_irecv(ops)
+
     def _complete(self, kind):
         if self.world == 1:
             return
         for w in self._work:
             w.wait()
         self._work = None
+        if self.direct:
+            return
         e, b = self.engine, self._bufs
         e.halo_unpack(kind, 0, b["recv_lo"].data_ptr())
         e.halo_unpack(kind, 1, b["recv_hi"].data_ptr())

@@ -160,6 +160,14 @@ int bflbm_step_finish(bflbm_ctx* c);
 int bflbm_halo_bytes(const bflbm_ctx* c, int kind, size_t* bytes_per_side);
 int bflbm_halo_pack(bflbm_ctx* c, int kind, int side, void* device_buf);
 int bflbm_halo_unpack(bflbm_ctx* c, int kind, int side, const void* device_buf);
+/* The same exchange WITHOUT staging: entry k of the face (k < *count = 38) is one contiguous component plane of
+ * *plane_bytes bytes at planes[k] in device memory -- pack != 0: where this slab's boundary planes hold what the neighbour
+ * across `side` needs; pack == 0: the halo plane on `side` that receives it (entry k of a sender's face pairs with entry
+ * k of the receiver's opposite face).  The addresses are those of the state buffer `kind` names at the time of the call
+ * (they alternate from step to step).  A transport that can post 38 sends per face (RCCL group, peer copies) needs no
+ * pack/unpack kernels and no buffers; bflbm_halo_pack/_unpack remain for transports that want one message per face.
+ * Replaces the same FillBoundary calls (LBM_binary.H:553-555). */
+int bflbm_halo_planes(bflbm_ctx* c, int kind, int side, int pack, void** planes, size_t* plane_bytes, int* count);
 
 /* ---- Single-process ring of slabs (the reference runs as ONE process, USE_MPI=FALSE, GNUmakefile:16):
  * nslabs z-slabs of one lattice, slab r on GPU devices[r % ndevices]; the +-z exchange of every step is

@@ -76,6 +76,14 @@ class StandinEngine:
     def _halo_array(self, kind):
         return self.S[self.cur] if kind == HALO_STATE else self.S[1 - self.cur]
 
+    def halo_plane_tensors(self, kind, side, pack, device=None):
+        """Staging-free exchange: the 38 component planes of a face as torch tensors that alias the state arrays."""
+        import torch
+        if getattr(self, "no_direct", False):
+            raise AttributeError("halo_plane_tensors")
+        A = self._halo_array(kind)
+        return [torch.from_numpy(A[comp, p]).reshape(-1) for comp, p in self._table(kind, side, pack)]
+
     def halo_pack(self, kind, side, ptr):
         plane = self.n[0] * self.n[1]
         buf = _buf(ptr, 2 * Q * plane).reshape(2 * Q, self.n[1], self.n[0])

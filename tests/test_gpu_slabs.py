@@ -106,9 +106,11 @@ def test_distributed_driver_world_size_one(pkg, ob):
         dist.destroy_process_group()
 
 
-def _gloo_gpu_worker(rank, world, port, outdir, n, steps, par):
+def _gloo_gpu_worker(rank, world, port, outdir, n, steps, par, staged=False, schedule=None):
     import os
     import sys
+    if staged:
+        os.environ["BFLBM_SLAB_STAGED"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import torch
@@ -117,7 +119,8 @@ def _gloo_gpu_worker(rank, world, port, outdir, n, steps, par):
     pkg = ge.load_package()
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    lat = pkg.SlabLattice(*n, params=pkg.default_params(**par), device=torch.device("cuda", 0))
+    lat = pkg.SlabLattice(*n, params=pkg.default_params(**par), device=torch.device("cuda", 0), schedule=schedule)
+    assert lat.direct == (not staged)
     lat.LBM_init_droplet(0.3)
     lat.LBM_timestep(steps)
     torch.cuda.synchronize()
@@ -129,10 +132,12 @@ def _gloo_gpu_worker(rank, world, port, outdir, n, steps, par):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_driver_ranks_sharing_one_gpu(ob, world):
-    """The real driver (slab.SlabLattice + HIP engine + torch.distributed P2P with device buffers),
-    `world` ranks on the one GPU of the test box over gloo (RCCL refuses several ranks per device)."""
+@pytest.mark.parametrize("world,staged", [(2, False), (3, False), (2, True)], ids=["2-direct", "3-direct", "2-staged"])
+def test_distributed_driver_ranks_sharing_one_gpu(ob, world, staged):
+    """The real driver (slab.SlabLattice + HIP engine + torch.distributed P2P on device memory), `world` ranks on the
+    one GPU of the test box over gloo (RCCL refuses several ranks per device).  Default transport: 38 plane-sized
+    sends and receives per face between the state buffers themselves (bflbm_halo_planes, no staging kernels);
+    BFLBM_SLAB_STAGED=1: pack -> one message per face -> unpack."""
     import socket
     import tempfile
     import torch.multiprocessing as mp
@@ -140,7 +145,7 @@ def test_distributed_driver_ranks_sharing_one_gpu(ob, world):
     n, steps, par = (10, 9, 16), 5, dict(kBT=1e-5, alpha0=2.0, seed=5)
     with tempfile.TemporaryDirectory() as d:
         mp.get_context("spawn")
-        mp.spawn(_gloo_gpu_worker, args=(world, port, d, n, steps, par), nprocs=world, join=True)
+        mp.spawn(_gloo_gpu_worker, args=(world, port, d, n, steps, par, staged), nprocs=world, join=True)
         ref = ob.OracleLattice(*n, params=ob.default_params(**par))
         ref.init_droplet(0.3)
         for _ in range(steps):
@@ -153,6 +158,59 @@ def test_distributed_driver_ranks_sharing_one_gpu(ob, world):
             _same(o["h"], ref.h[:, z0:z1], f"rank {r} hydrovs")
             np.testing.assert_allclose(o["com"], ref.com(), rtol=1e-12)
             np.testing.assert_allclose(o["mass"], [ref.hbar[0].sum(), ref.hbar[1].sum()], rtol=1e-12)
+
+
+def test_distributed_driver_with_the_handover_schedule(ob):
+    """Two ranks (one GPU, gloo), a lattice of full tiles, the hand-over kernel in every slab's interior sweep and
+    boundary pairs, plane-sized sends between the state buffers: the oracle at tolerance."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    import tolerances
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    n, steps, par = (128, 12, 24), 12, dict(alpha0=2.0)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_gloo_gpu_worker, args=(2, port, d, n, steps, par, False, "handover"), nprocs=2, join=True)
+        ref = ob.OracleLattice(*n, params=ob.default_params(**par))
+        ref.init_droplet(0.3)
+        for _ in range(steps):
+            ref.timestep()
+        exact = True
+        for r in range(2):
+            o = np.load(os.path.join(d, f"r{r}.npz"))
+            z0, z1 = int(o["z0"]), int(o["z1"])
+            tolerances.check(o["h"], ref.h[:, z0:z1], f"rank {r}")
+            assert np.abs(o["f"] - ref.f[:, z0:z1]).max() < 1e-13
+            exact = exact and np.array_equal(o["f"], ref.f[:, z0:z1])
+        assert not exact                                   # the frames were in use
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), rehearsed with both
+    ranks on the one GPU of this box over gloo: the N > 1 bench path with the hand-over schedule (what auto runs on the
+    512^3 slabs of the real bench) and the staging-free exchange runs, reports one JSON line with n_gpus 2, conserves the
+    mass of the stripe and states the halo size.  A rehearsal of the code path, never a measurement."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, BFLBM_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--shape", "128,16,12", "--no-cpu-baseline", "--schedule", "handover"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 2 and r["config"]["schedule"] == "handover" and r["scaling"] == "weak"
+    assert r["config"]["workload"].startswith("128x16x24")
+    assert r["config"]["halo_bytes_per_face"] == 38 * 128 * 16 * 8
+    rho, phi = r["config"]["mass_check"]
+    assert abs(rho + phi - 128 * 16 * 24) < 1e-6            # rho + phi = rho_hi + rho_lo = 1 at every site of a stripe
+    assert len(r["spread"]["blocks_ms_per_step"]) == 3 and r["value"] > 0
 
 
 @pytest.mark.parametrize("schedule", ["two_pass", "fused"])
@@ -204,3 +262,25 @@ def test_native_ring_256_matches_single_context(pkg):
     hr = r.LBM_hydrovars_density()
     r.close()
     assert np.array_equal(ha, hr)
+
+
+def test_native_ring_per_plane_copy_fallback():
+    """the native ring has two transports -- k_halo_pull reading the neighbour's planes in place (peer
+    mappings between GPUs) and 76 hipMemcpyPeerAsync per slab where no peer mapping exists.  On a one-GPU box the
+    second never ran; BFLBM_RING_COPY_FALLBACK=1 forces it (fresh process: the switch is read once).  Both equal
+    the oracle bit for bit; placement on more than one GPU stays unverified here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import __graft_entry__ as ge, oracle_binding as ob\n"
+            "pkg = ge.load_package()\n"
+            "n = (70, 9, 16); par = dict(kBT=1e-5, alpha0=2.0)\n"
+            "r = pkg.RingLBM(*n, nslabs=3, params=pkg.default_params(**par), schedule='two_pass')\n"
+            "r.LBM_init_droplet(0.3); r.LBM_timestep(6); f, g = r.populations(); r.close()\n"
+            "o = ob.OracleLattice(*n, params=ob.default_params(**par)); o.init_droplet(0.3)\n"
+            "[o.timestep() for _ in range(6)]\n"
+            "print('EQUAL', bool(np.array_equal(f, o.f) and np.array_equal(g, o.g)))\n") % (root, os.path.join(root, "tests"))
+    for env in ({}, {"BFLBM_RING_COPY_FALLBACK": "1"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "EQUAL True" in out.stdout, (env, out.stdout[-500:], out.stderr[-1500:])

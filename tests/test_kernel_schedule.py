@@ -27,7 +27,7 @@ def device_asm(tmp_path_factory):
 
 
 def _kernel(lines, mode):
-    start = [i for i, l in enumerate(lines) if re.match(r"^_Z10k_fused_hoILi4ELi%dE.*:" % mode, l)][0]
+    start = [i for i, l in enumerate(lines) if re.match(r"^_Z10k_fused_hoILi4ELi%dELb0EE.*:" % mode, l)][0]
     end = [i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end")][0]
     meta = "\n".join(lines[end:end + 120])
     return lines[start:end], meta

@@ -20,7 +20,9 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, outdir, case):
+def _worker(rank, world, port, outdir, case, staged=False):
+    if staged:
+        os.environ["BFLBM_SLAB_STAGED"] = "1"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -34,6 +36,7 @@ def _worker(rank, world, port, outdir, case):
     params = ob.default_params(**par)
     fac = lambda nx, ny, nz, z0, z1, r, w: StandinEngine(nx, ny, nz, z0, z1, r, w, params)
     lat = pkg.SlabLattice(*n, engine_factory=fac, device="cpu")
+    assert lat.direct == (not staged)          # default: sends and receives between the state arrays themselves
     if upload:
         full = ob.OracleLattice(*n, params=params)
         full.init_droplet(0.3)
@@ -67,13 +70,16 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("staged", [False, True], ids=["direct", "staged"])
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("case", CASES)
-def test_slab_lattice_over_gloo_matches_single_box(ob, world, case):
+def test_slab_lattice_over_gloo_matches_single_box(ob, world, case, staged):
+    """Both transports of slab.SlabLattice: 38 plane-sized sends per face straight between the state arrays (default),
+    and pack -> one message per face -> unpack."""
     import torch.multiprocessing as mp
     n, init, steps, par, upload = case
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), d, case), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), d, case, staged), nprocs=world, join=True)
         params = ob.default_params(**par)
         ref = ob.OracleLattice(*n, params=params)
         if upload:

@@ -41,6 +41,19 @@ def traffic_from_summary(path, prefixes):
     return fetch * 1024 * 2, write * 1024
 
 
+def kernel_avg_ms(path, prefixes):
+    """Sum over the step's kernels of the AverageNs column of a rocprofv3 --kernel-trace --stats summary."""
+    import csv
+    total = 0.0
+    rows = list(csv.DictReader(open(path)))
+    for pre in prefixes:
+        hits = [r for r in rows if r["Name"].startswith(pre) or (" " + pre) in (" " + r["Name"])[:48]]
+        if len(hits) != 1:
+            raise SystemExit(f"{path}: {len(hits)} kernels match '{pre}'")
+        total += float(hits[0]["AverageNs"]) * 1e-6
+    return total
+
+
 if __name__ == "__main__":
     tag, key, schedule, kname = sys.argv[1:5]
     src, dst = os.path.join("gpurun_out", tag), "profiles"
@@ -52,7 +65,10 @@ if __name__ == "__main__":
     read_b, write_b = traffic_from_summary(summary, kname.split(","))
     path = os.path.join(dst, "traffic.json")
     t = json.load(open(path)) if os.path.exists(path) else {}
+    stats = os.path.join(dst, f"{tag}_kernel_stats.csv")
     t[f"{key}|{schedule}"] = {"hbm_bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b,
+                              "kernel_avg_ms": round(kernel_avg_ms(stats, kname.split(",")), 4) if os.path.exists(stats) else None,
+                              "kernel_stats": stats,
                               "source": summary, "kernel": kname,
                               "rule": "median FETCH_SIZE KiB x1024 x2 (gfx950 half-count, calibrated on k_pull/k_density) + median WRITE_SIZE KiB x1024, from the source file alone"}
     json.dump(t, open(path, "w"), indent=1)
