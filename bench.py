@@ -138,24 +138,44 @@ def main():
     def run_case(sx, sy, sz):
         """Time a.steps steps on a lattice of sx x sy x (sz*world); returns the result fields of this case (rank 0)."""
         nx, ny, nz = sx, sy, sz * world
+        transport = None
         if use_dist:
-            lat = pkg.SlabLattice(nx, ny, nz, params=params, schedule=a.schedule)
-            eng = lat.engine
-
             def barrier():
                 torch.cuda.synchronize()
                 dist.barrier()
                 torch.cuda.synchronize()
+
+            def make_and_warm():
+                lat_ = pkg.SlabLattice(nx, ny, nz, params=params, schedule=a.schedule)
+                try:
+                    getattr(lat_, "LBM_init_" + a.init)(*([0.5] if a.init == "stripe" else [0.2] if a.init == "droplet" else []))
+                    lat_.LBM_timestep(a.warmup)
+                    barrier()
+                except Exception:
+                    lat_.close()                   # 87 GB per rank at the default size
+                    raise
+                return lat_
+            try:
+                lat = make_and_warm()
+            except Exception as exc:               # noqa: BLE001
+                # the staging-free transport (plane-sized sends between the state buffers) has only met gloo so far; if
+                # RCCL refuses it, fall back to one packed message per face rather than lose the measurement -- all
+                # ranks see the same error class at the same call, and the line says which transport ran
+                print(f"[bench] rank {rank}: direct halo transport failed ({exc!r}); retrying staged", file=sys.stderr)
+                os.environ["BFLBM_SLAB_STAGED"] = "1"
+                lat = make_and_warm()
+            transport = "direct (38 plane-sized sends per face from the state buffers)" if lat.direct else "staged (pack, one message per face, unpack)"
+            eng = lat.engine
         else:
             lat = pkg.BinaryLBM(nx, ny, nz, params=params, device=local_rank, schedule=a.schedule)
             eng = lat
 
             def barrier():
                 eng.sync()
+            getattr(lat, "LBM_init_" + a.init)(*([0.5] if a.init == "stripe" else [0.2] if a.init == "droplet" else []))
+            lat.LBM_timestep(a.warmup)
 
         eng_schedule = eng.resolved_schedule() if hasattr(eng, "resolved_schedule") else a.schedule    # what auto resolves to
-        getattr(lat, "LBM_init_" + a.init)(*([0.5] if a.init == "stripe" else [0.2] if a.init == "droplet" else []))
-        lat.LBM_timestep(a.warmup)
         # EXACTLY a.steps steps per timed block, each block bracketed by barrier + device synchronisation on both sides and
         # reduced with MAX over the ranks; the block is repeated a.blocks times and the MEDIAN block is the reported one
         # (boxes of the pool, and runs on one box, scatter by a few percent: `spread` shows the blocks).
@@ -212,7 +232,7 @@ def main():
         return {
             "value": round(sites * a.steps / wall / 1e6, 1), "ms_per_step": round(wall / a.steps * 1e3, 4),
             "workload": workload, "schedule": schedule, "slab_per_gpu": f"{nx}x{ny}x{nz // world}", "spread": spread,
-            "mass_check": [rho_sum, phi_sum], "halo_bytes_per_face": halo_bytes,
+            "mass_check": [rho_sum, phi_sum], "halo_bytes_per_face": halo_bytes, "halo_transport": transport,
             "halo_overlap": None if seq_ms is None else {"ms_per_step_overlapped": round(wall / a.steps * 1e3, 4),
                                                           "ms_per_step_exchange_after_sweep": round(seq_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -248,6 +268,7 @@ def main():
             "config": {"workload": res["workload"], "schedule": res["schedule"], "slab_per_gpu": res["slab_per_gpu"],
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
                        "mass_check": res["mass_check"], "halo_bytes_per_face": res["halo_bytes_per_face"],
+                       "halo_transport": res["halo_transport"],
                        "halo_overlap": res["halo_overlap"], "also": also or None},
             "roofline": res["roofline"],
         }

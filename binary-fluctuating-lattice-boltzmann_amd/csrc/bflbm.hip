@@ -225,10 +225,10 @@ inline bool handover_contract_params(const bflbm_params& p) {
 // Where `auto` expects schedule 3 to be the faster one (A/B on MI355X, tools/ragged_ab.sh):
 // it needs marches of at least 16 planes per workgroup (64^3: 16 tile columns cut into chunks of 4 planes, of whose 6
 // positions only 2 read frames: -13 %; 64 x 64 x 256 and 128 x 128 x 64, chunks of 16: equal or better), and at zero
-// noise, where the alternative is the one-pass schedule 1, whole tile rows (a lower last row puts three tile rows on the
-// pulled ring: 250^3 -3 %, 256 x 250 x 256 -2 %) and a last tile column that is not mostly idle lanes (96^3: 75 % of
-// the lanes busy, -9 %; 200^3: 78 %, +4 %; 300^3: +11 ... 18 %).  With noise the alternative is the two-pass schedule
-// and the hand-over kernel wins on every ragged lattice measured (250^3 +18 %).  BFLBM_AUTO_MIN_LZ overrides the 16.
+// noise, where the alternative is the one-pass schedule 1, a last tile column that is not mostly idle lanes (96^3: 75 %
+// of the lanes busy, -9 %; 200^3: 78 %, +4 %; 300^3: +13 %; 250^3 with a last tile row of two rows: +9 %).  With noise the
+// alternative is the two-pass schedule and the hand-over kernel wins on every ragged lattice measured (250^3 +25 %).
+// BFLBM_AUTO_MIN_LZ overrides the 16.
 inline bool handover_worthwhile(const bflbm_ctx* c, bool noisy) {
   static const int min_lz = [] { const char* e = getenv("BFLBM_AUTO_MIN_LZ"); return e ? atoi(e) : 16; }();
   const int lo = c->G.H, hi = c->G.H + c->nzl;
@@ -237,7 +237,7 @@ inline bool handover_worthwhile(const bflbm_ctx* c, bool noisy) {
   if (F.lz < min_lz) return false;
   if (noisy) return true;
   const double lanes_busy = (double)c->G.nx / (64.0 * F.ntx);
-  return c->G.ny % BFLBM_HO_TY == 0 && lanes_busy >= 0.77;
+  return lanes_busy >= 0.77;
 }
 
 // 0 two-pass, 1 fused (pulled ring), 3 hand-over.  The bit-exact choice is 1 at zero noise and 0 with noise.

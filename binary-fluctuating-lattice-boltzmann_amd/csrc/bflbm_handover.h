@@ -33,9 +33,11 @@
 //   x  the last tile of a row may be narrower (aw < 64 sites): its idle lanes load a duplicate of the last site, store
 //      nothing and contribute zeros to the x shifts; its right column lane is aw-1 and its right ring column aw+1, and
 //      the frames keep their layout (slots are roles, not coordinates), so a narrow tile hands over like any other.
-//   y  the last tile row may be lower (ah < TY rows).  The y roles of the producer need TY >= 4 distinct rows, so that
-//      tile row produces no frames and pulls its ring, and the two tile rows next to it (above, periodically, and below)
-//      pull theirs too while still producing: three tile rows out of ny/TY on the pulled ring, the rest unchanged.
+//   y  the last tile row may be lower (ah < TY rows).  In a full tile every row has ONE y role (bottom edge, hands its -y
+//      sum down, hands its +y sum up, top edge); in a tile of 2 or 3 rows a row has two (ah = 2: row 0 is the bottom
+//      edge AND hands its +y sum to row 1), so the ragged kernel runs both travelling sums in every row and picks by
+//      role; the frame keeps its layout with the top row / top ring row at ah-1 / ah.  (ah = 1, like aw = 1, is
+//      refused by the host: a ring site owned by such a tile also collects from the tile beyond it.)
 // A ring site is looked up by its coordinates RELATIVE to each of the 3 x 3 surrounding tiles (not by wrapped global
 // coordinates), so a lattice one tile wide or high -- where the neighbour on both sides is the tile itself and a ring
 // site is one of its own edge sites at the same time -- needs nothing special: nx >= 64 (one tile: nx = 64), ny >= TY.
@@ -62,9 +64,9 @@ struct HoGrid {
 };
 
 // destination slot of lattice site (lx,ly), given relative to a tile's origin, in that tile's frame; -1: none
-template <int TY>
-__device__ __forceinline__ int ho_frame_slot(int lx, int ly, int TX /* width of the tile that owns the frame */) {
-  using L = HoLayout<TY>;
+template <int TYL>
+__device__ __forceinline__ int ho_frame_slot(int lx, int ly, int TX /* width */, int TY /* height of the tile that owns the frame */) {
+  using L = HoLayout<TYL>;
   if (lx >= 0 && lx < TX && ly >= 0 && ly < TY) {
     if (ly == 0) return L::EB + lx;
     if (ly == TY - 1) return L::ET + lx;
@@ -143,13 +145,10 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   const bool active_x = !RAG || tx < aw;
   const bool active = !RAG || (tx < aw && ty < ah);
   const int x = x0 + (RAG ? min(tx, aw - 1) : tx), y = y0 + (RAG ? min(ty, ah - 1) : ty);
-  // frames: produced unless this is the lower last tile row; consumed unless that row is this one or a y neighbour
-  bool produce = true, consume = true;
-  if (RAG && G.ny % TY != 0) {
-    const int last = F.nty - 1, up = tiy == last ? 0 : tiy + 1, dn = tiy == 0 ? last : tiy - 1;
-    produce = tiy != last;
-    consume = produce && up != last && dn != last;
-  }
+  // y roles of this row in a ragged tile (wave-uniform; a full tile has exactly one per row, see row_down / row_up below)
+  const bool r_bot = RAG && ty == 0, r_top = RAG && ty == ah - 1;           // edge rows: own sums -> E, travelling sum -> O
+  const bool r_hdn = RAG && ah >= 2 && ty == 1;                            // its -y travelling sum completes row 0's E
+  const bool r_hup = RAG && ah >= 2 && ty == ah - 2;                       // its +y travelling sum completes row ah-1's E
   const unsigned xo[3] = { (unsigned)wrapx(x - 1) * 8u, (unsigned)x * 8u, (unsigned)wrapx(x + 1) * 8u };
   const unsigned yo[3] = { (unsigned)(wrapy(y - 1) * G.pitch) * 8u, (unsigned)(y * G.pitch) * 8u, (unsigned)(wrapy(y + 1) * G.pitch) * 8u };
   const int lown = (ty + 1) * LW + (tx + 1);
@@ -168,13 +167,13 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   // 512-byte frame rows, four full lines per load.  The 4 corners and 2*TY column sites, which have up to four
   // pieces in scattered places, go to lanes of wave 2.  (Spread evenly over the four waves, every wave issued all
   // eight frame loads on parts of those rows: twice the instructions and half again the line requests.)
-  const bool has_rtask = (ty < 2 && lane < aw) || (ty == 2 && lane < 4 + 2 * TY);
+  const bool has_rtask = (ty < 2 && lane < aw) || (ty == 2 && lane < 4 + 2 * ah);
   int hlx = 0, hly = 0;
   if (ty == 0) { hlx = lane + 1; hly = 0; }
-  else if (ty == 1) { hlx = lane + 1; hly = TY + 1; }
-  else if (ty == 2 && lane < 4) { hlx = (lane & 1) ? aw + 1 : 0; hly = (lane & 2) ? TY + 1 : 0; }
-  else if (ty == 2 && lane < 4 + TY) { hlx = 0; hly = lane - 4 + 1; }
-  else if (ty == 2 && lane < 4 + 2 * TY) { hlx = aw + 1; hly = lane - 4 - TY + 1; }
+  else if (ty == 1) { hlx = lane + 1; hly = ah + 1; }
+  else if (ty == 2 && lane < 4) { hlx = (lane & 1) ? aw + 1 : 0; hly = (lane & 2) ? ah + 1 : 0; }
+  else if (ty == 2 && lane < 4 + ah) { hlx = 0; hly = lane - 4 + 1; }
+  else if (ty == 2 && lane < 4 + 2 * ah) { hlx = aw + 1; hly = lane - 4 - ah + 1; }
   const int lhalo = hly * LW + hlx;
   // the frames that hold a piece of this ring site: the owner's E and the O of every other tile around it.  The site
   // is (hlx-1, hly-1) in this tile's coordinates, hence (that - offset of the tile) in the coordinates of each of the
@@ -182,17 +181,17 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   // REPRESENTATIONS of the site in that tile's frame, and at most one of them names a slot per piece.
   unsigned fo[4] = {0u, 0u, 0u, 0u};
   int nfo = 0;
-  if (has_rtask && consume) {
-    const int wlast = G.nx - (F.ntx - 1) * TX;               // width of the last tile column (TX when full)
+  if (has_rtask) {
+    const int wlast = G.nx - (F.ntx - 1) * TX, hlast = G.ny - (F.nty - 1) * TY;   // extent of the last tile column / row (TX, TY when full)
     for (int dty = -1; dty <= 1; ++dty) {
       for (int dtx = -1; dtx <= 1; ++dtx) {
         int ux = tix + dtx, uy = tiy + dty;
         ux = ux < 0 ? ux + F.ntx : (ux >= F.ntx ? ux - F.ntx : ux);
         uy = uy < 0 ? uy + F.nty : (uy >= F.nty ? uy - F.nty : uy);
-        const int wu = (ux == F.ntx - 1) ? wlast : TX;
+        const int wu = (ux == F.ntx - 1) ? wlast : TX, hu = (uy == F.nty - 1) ? hlast : TY;
         const int lx = (hlx - 1) + (dtx < 0 ? wu : (dtx > 0 ? -aw : 0));
-        const int ly = (hly - 1) - dty * TY;
-        const int slot = ho_frame_slot<TY>(lx, ly, wu);
+        const int ly = (hly - 1) + (dty < 0 ? hu : (dty > 0 ? -ah : 0));
+        const int slot = ho_frame_slot<TY>(lx, ly, wu, hu);
         if (slot >= 0 && nfo < 4) { fo[nfo] = (unsigned)((uy * F.ntx + ux) * L::REC + slot) * 8u; ++nfo; }
       }
     }
@@ -209,34 +208,43 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   const int fa = qa + 1, fb = qb - 2;                        // [fa, fb]
 
   double anb[2][2] = {{0., 0.}, {0., 0.}};                   // [fluid][stage] z pipeline of the row's travelling sum
+  double aup[2][2] = {{0., 0.}, {0., 0.}};                   // RAG: the +y travelling sum runs beside the -y one (anb)
 
   // finish the frames of plane tpf from what the previous march position left in LDS (after a barrier)
   auto finish = [&](int tpf, int rb) {
-    if (tpf < fa || tpf > fb || !produce) return;
+    if (tpf < fa || tpf > fb) return;
     double* __restrict__ fp = Hg.fout + (long long)tpf * Hg.fplane;
-    if (edge_row) {
+    if (!RAG) {
+      if (edge_row) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const double e = exch[rb][k][side_y][0][lane] + exch[rb][k][side_y][1][lane];
+          st(fp, tile_rec + (unsigned)(k * L::FR + (side_y ? L::ET : L::EB) + lane) * 8u, e);
+        }
+      }
+    } else {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const double e = exch[rb][k][side_y][0][lane] + exch[rb][k][side_y][1][lane];
-        st(fp, tile_rec + (unsigned)(k * L::FR + (side_y ? L::ET : L::EB) + lane) * 8u, e);
+        if (r_bot) st(fp, tile_rec + (unsigned)(k * L::FR + L::EB + lane) * 8u, exch[rb][k][0][0][lane] + exch[rb][k][0][1][lane]);
+        if (r_top) st(fp, tile_rec + (unsigned)(k * L::FR + L::ET + lane) * 8u, exch[rb][k][1][0][lane] + exch[rb][k][1][1][lane]);
       }
     }
     if (ty == 0 && lane < 8 * TY) {
       const int k = lane / (4 * TY), rem = lane % (4 * TY), sd = rem / (2 * TY), u = rem % (2 * TY);
-      double v; int slot;
-      if (u < TY - 2) {                                        // own edge site of the column, rows 1..TY-2
+      const int ne = ah > 2 ? ah - 2 : 0;                      // own edge sites of the column: rows 1..ah-2
+      double v = 0.; int slot = -1;
+      if (u < ne) {
         const int row = u + 1;
         v = colfin[rb][k][sd][row][0] + colfin[rb][k][sd][row - 1][1] + colfin[rb][k][sd][row + 1][2];
         slot = (sd ? L::ER : L::EL) + row - 1;
-      } else {                                                 // ring site beside the column, rows -1..TY
-        const int row = u - (TY - 2) - 1;
-        v = 0.;
-        if (row >= 0 && row < TY) v = colfin[rb][k][sd][row][3];
-        if (row - 1 >= 0 && row - 1 < TY) v += colfin[rb][k][sd][row - 1][4];
-        if (row + 1 >= 0 && row + 1 < TY) v += colfin[rb][k][sd][row + 1][5];
+      } else if (u - ne < ah + 2) {                            // ring site beside the column, rows -1..ah
+        const int row = u - ne - 1;
+        if (row >= 0 && row < ah) v = colfin[rb][k][sd][row][3];
+        if (row - 1 >= 0 && row - 1 < ah) v += colfin[rb][k][sd][row - 1][4];
+        if (row + 1 >= 0 && row + 1 < ah) v += colfin[rb][k][sd][row + 1][5];
         slot = (sd ? L::OR_ : L::OL) + row + 1;
       }
-      st(fp, tile_rec + (unsigned)(k * L::FR + slot) * 8u, v);
+      if (slot >= 0) st(fp, tile_rec + (unsigned)(k * L::FR + slot) * 8u, v);
     }
   };
 
@@ -256,7 +264,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       if (which != 2) f[i] = ld(b, o);
       if (which != 1) g[i] = ld(b + (long long)Q * G.vol, o);
     }
-    if (which != 2 && Hg.use_frames && consume && q >= fa && q <= fb && has_rtask) {
+    if (which != 2 && Hg.use_frames && q >= fa && q <= fb && has_rtask) {
       const double* __restrict__ fp = Hg.fin + (long long)q * Hg.fplane;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -291,7 +299,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     for (int i = 0; i < Q; ++i) { cf[i] = nf[i]; cg[i] = ng[i]; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { hv[0][j] = hvn[0][j]; hv[1][j] = hvn[1][j]; }
-    const bool ring_from_frames = Hg.use_frames && consume && q >= fa && q <= fb;       // uniform over the workgroup
+    const bool ring_from_frames = Hg.use_frames && q >= fa && q <= fb;       // uniform over the workgroup
     double zero = 0.0;
     asm volatile("" : "+v"(zero));
     auto density = [&](const double (&fs)[Q]) { double r = zero;
@@ -395,7 +403,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       double v_b[3];
       d_barycentric(r, ph, Hy, v_b, R);
       const int tp = pc - 1;                                   // plane whose sums become complete now
-      const bool tp_ok = produce && tp >= fa && tp <= fb;
+      const bool tp_ok = tp >= fa && tp <= fb;
       double* __restrict__ fp = Hg.fout + (long long)tp * Hg.fplane;
       const int wb = it & 1;
       const double zn[Q] = {0.};
@@ -432,6 +440,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
         put(11, o11); put(12, o12); put(13, o13); put(14, o14);
         // what leaves the tile in x (column lanes only; side_x picks the lane's outward direction)
         const double oxp = side_x ? o15 : o18, ox0 = side_x ? o1 : o2, oxm = side_x ? o17 : o16, oyp = side_x ? o7 : o10, oym = side_x ? o9 : o8;
+        if (!RAG) {
         // travelling sum towards the nearer tile edge (rows 0,1: -y; rows TY-2,TY-1: +y): contributions to
         // planes p+1, p, p-1 enter a two-stage pipeline, what leaves it is complete for plane p-1
         const double np = row_down ? o14 : o11, n0 = row_down ? xm0 : xp0, nm = row_down ? o12 : o13;
@@ -447,6 +456,25 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
           if (tp_ok) st(fp, tile_rec + (unsigned)(k * L::FR + (side_y ? L::OT : L::OB) + lane) * 8u, fin_nb);
         }
         if (TY == 4 || row_kind) exch[wb][k][side_y][edge_row ? 0 : 1][lane] = hand;
+        } else {
+        // ragged tile (1-4 rows): both travelling sums run in every row; what a row does with them is its role(s)
+        const double fin_dn = anb[k][1] + o12;    // -y: lands on row ty-1 (the ring row below for row 0)
+        anb[k][1] = anb[k][0] + xm0;
+        anb[k][0] = o14;
+        const double fin_up = aup[k][1] + o13;    // +y: lands on row ty+1 (the ring row above for row ah-1)
+        aup[k][1] = aup[k][0] + xp0;
+        aup[k][0] = o11;
+        if (r_bot || r_top) {                     // own sums of an edge row (one pipeline: a single-row tile is both edges)
+          const int sd = r_bot ? 0 : 1;
+          const double fin_self = accs[1][k][sd][lane] + x0m;
+          accs[1][k][sd][lane] = accs[0][k][sd][lane] + x00;
+          accs[0][k][sd][lane] = x0p;
+          if (r_bot) { exch[wb][k][0][0][lane] = fin_self; if (tp_ok) st(fp, tile_rec + (unsigned)(k * L::FR + L::OB + lane) * 8u, fin_dn); }
+          if (r_top) { exch[wb][k][1][0][lane] = fin_self; if (tp_ok) st(fp, tile_rec + (unsigned)(k * L::FR + L::OT + lane) * 8u, fin_up); }
+        }
+        if (r_hdn) exch[wb][k][0][1][lane] = fin_dn;
+        if (r_hup) exch[wb][k][1][1][lane] = fin_up;
+        }
         if (col_lane) {
           // kinds: 0..2 sums travelling dy = 0,+1,-1 inside the column; 3..5 what leaves the tile in x with dy = 0,+1,-1
           const double vp[6] = { x0p, o11, o14, oxp, 0., 0. };
@@ -491,11 +519,12 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
 #define BFLBM_HO_TY 4
 #endif
 
-// lattices the hand-over kernel takes: at least one whole tile; a narrower last tile column needs two lanes (its left
-// and right column roles must be different lanes)
+// lattices the hand-over kernel takes: at least one whole tile; a narrower last tile column / lower last tile row needs
+// two lanes / rows (a ring site owned by a tile ONE site wide or high also collects from the tile beyond it, which the
+// 3 x 3 lookup of the consumer does not reach, and its two edge roles must be different lanes / rows)
 static inline bool handover_ok(const Geo& G) {
   constexpr int TY = BFLBM_HO_TY;
-  return G.nx >= 64 && (G.nx % 64 == 0 || G.nx % 64 >= 2) && G.ny >= TY;
+  return G.nx >= 64 && G.nx % 64 != 1 && G.ny >= TY && G.ny % TY != 1;
 }
 static inline bool handover_ragged(const Geo& G) { return G.nx % 64 != 0 || G.ny % BFLBM_HO_TY != 0; }
 static inline size_t handover_frame_doubles(const Geo& G) {
@@ -518,11 +547,7 @@ static inline void handover_plan(const Geo& G, int pa, int pb, int pair_len, Fus
   static const int want_env = [] { const char* e = getenv("BFLBM_FUSED_WG"); return e ? atoi(e) : 0; }();
   const int slots = g_fused_ncu > 0 ? g_fused_ncu : 256;        // one workgroup per CU
   static const int min_slab_rounds = [] { const char* e = getenv("BFLBM_SLAB_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
-  // A lower last tile row puts three tile rows on the pulled ring (1.3x the time of the others, measured on the first
-  // step of every run).  In a single round those workgroups ARE the launch time (250^3: 5584 MLUPS against 6444 for
-  // schedule 1); with three rounds or more, and those rows first in the order, they overlap with the rest.
-  const bool low_row = G.ny % TY != 0;
-  F.row0 = low_row ? std::max(0, F.nty - 2) : 0;
+  F.row0 = 0;
   const int maxchunks = std::max(1, np / 4);                     // a chunk shorter than 4 planes has no complete frame
   int nchunks;
   if (want_env > 0) {
@@ -534,7 +559,7 @@ static inline void handover_plan(const Geo& G, int pa, int pb, int pair_len, Fus
       if (chunks != k) continue;
       if (G.zwrap && lz > 256 && k < maxchunks) continue;   // one 512-plane march per column was A/B-tested: -1 %
       const long long total = (long long)F.ncols * chunks, rounds = (total + slots - 1) / slots;
-      if ((!G.zwrap || low_row) && rounds < min_slab_rounds && k < maxchunks) continue;
+      if (!G.zwrap && rounds < min_slab_rounds && k < maxchunks) continue;
       const long long cost = rounds * (lz + 1);
       if (best < 0 || cost < best) { best = cost; nchunks = k; }
     }

@@ -30,12 +30,11 @@ def _tolerances(h, href, what=""):
 
 
 def frames_expected(shape, nslabs=1):
-    """Some tile row reads its ring from frames: a launch of at least 4 planes (chunks are never shorter; the interior
-    sweep of a slab is its planes minus the two boundary pairs) and either whole tile rows or at least four of them (a
-    lower last tile row and its two neighbours pull their ring: bit-exact like schedule 1)."""
+    """The ring densities come from frames somewhere: a launch of at least 4 planes (chunks are never shorter; the
+    interior sweep of a slab is its planes minus the two boundary pairs)."""
     nx, ny, nz = shape
     planes = nz if nslabs == 1 else nz // nslabs - 4
-    return planes >= 4 and (ny % 4 == 0 or -(-ny // 4) >= 4)
+    return planes >= 4
 
 
 def droplet_radius(shape):
@@ -94,10 +93,11 @@ SHAPES = [(128, 8, 4), (128, 28, 5), (128, 40, 26), (192, 8, 9), (192, 28, 27), 
 
 
 # lattices that are not whole 64 x 4 tiles (round 3): one tile wide (64: the x neighbour on both sides is the tile itself),
-# one tile high, a narrower last tile column (aw = 2 ... 58 lanes), a lower last tile row (1 ... 3 rows: that tile row and
-# its two neighbours pull their ring), both at once; the reference's own box widths 64 and 256 among them
+# one tile high, a narrower last tile column (aw = 2 ... 58 lanes), a lower last tile row (1 ... 3 rows, whose rows have
+# two or three producer roles each), both at once; the reference's own box widths 64 and 256 among them
 RAGGED = [(64, 8, 9), (64, 4, 10), (128, 4, 8), (64, 64, 12), (300, 12, 10), (100, 8, 9), (66, 8, 8), (250, 12, 9),
-          (128, 10, 9), (192, 13, 8), (128, 7, 10), (250, 10, 9), (122, 6, 27), (64, 5, 8), (186, 31, 5)]
+          (128, 10, 9), (192, 14, 8), (128, 7, 10), (250, 10, 9), (122, 6, 27), (64, 6, 8), (186, 31, 5), (128, 18, 9),
+          (64, 6, 12), (130, 7, 10), (128, 11, 26), (250, 250, 8)]
 
 
 @pytest.mark.parametrize("shape", SHAPES + RAGGED, ids=lambda s: "x".join(map(str, s)))
@@ -284,10 +284,13 @@ def test_auto_stays_exact_when_asked_or_out_of_range(pkg):
         assert l.resolved_schedule() == "fused"
     with pkg.BinaryLBM(256, 256, 32, params=pkg.default_params(alpha0=1.7, rho_hi=3.0)) as l:
         assert l.resolved_schedule() == "handover"
+    for shape in ((128, 13, 8), (129, 12, 8)):               # a last tile row / column of ONE site: refused, resolves to the exact schedule
+        with pkg.BinaryLBM(*shape, schedule="handover") as l:
+            assert l.resolved_schedule() == "fused"
     # where the hand-over kernel is not the faster one auto stays on the one-pass exact schedule: marches
-    # shorter than 16 planes, a lower last tile row or a mostly idle last tile column at zero noise
-    for shape, par, want in (((64, 64, 64), {}, "fused"), ((64, 64, 256), {}, "handover"), ((256, 250, 256), {}, "fused"),
-                             ((256, 250, 256), dict(kBT=1e-5), "handover"), ((300, 300, 96), {}, "handover"), ((96, 96, 384), {}, "fused")):
+    # shorter than 16 planes, or a mostly idle last tile column at zero noise
+    for shape, par, want in (((64, 64, 64), {}, "fused"), ((64, 64, 256), {}, "handover"), ((256, 250, 256), {}, "handover"),
+                             ((96, 96, 384), dict(kBT=1e-5), "handover"), ((300, 300, 96), {}, "handover"), ((96, 96, 384), {}, "fused")):
         with pkg.BinaryLBM(*shape, params=pkg.default_params(**par)) as l:
             assert l.resolved_schedule() == want, (shape, par)
 
