@@ -685,6 +685,16 @@ int bflbm_step(bflbm_ctx* c, int nsteps) {
   return 0;
 }
 
+#ifdef BFLBM_STAMP
+// diagnostic build only: the phase stamps of the hand-over kernel (tools/ho_stamps.py)
+int bflbm_debug_ho_stamps(unsigned long long* out, int n) {
+  if (!out || n > 4 * HO_STAMP_POS * HO_NSTAMP) return fail("bad argument");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ho_stamps), (size_t)n * sizeof(unsigned long long)));
+  return 0;
+}
+#endif
+
 int bflbm_step_count(const bflbm_ctx* c, long long* n) {
   if (!c || !n) return fail("null argument");
   *n = c->steps;

@@ -46,6 +46,23 @@
 
 #include "bflbm_fused.h"
 
+// Requests of the next plane's f half (quiet kernel): one every BFLBM_HO_SPREAD_F VALU instructions of the relaxation of
+// fluid f instead of one burst of 19 before it; 0 = burst (see the comment at the call site)
+#ifndef BFLBM_HO_SPREAD_F
+#define BFLBM_HO_SPREAD_F 30
+#endif
+
+// Diagnostic build (-DBFLBM_STAMP, tools/ho_stamps.py): shader-clock stamps at the phase boundaries of a march position,
+// written by lane 0 of every wave of ONE workgroup for 64 steady-state positions.  Not compiled into the product.
+#ifdef BFLBM_STAMP
+#define HO_NSTAMP 10
+#define HO_STAMP_POS 64
+__device__ unsigned long long g_ho_stamps[4 * HO_STAMP_POS * HO_NSTAMP];
+#define HO_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); ts[k] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define HO_STAMP(k) do { } while (0)
+#endif
+
 template <int TY> struct HoLayout {
   static constexpr int TX = 64;
   // slots of one fluid's frame (doubles): the four 64-entry rows first, each on its own 128-byte lines (they are stored
@@ -249,7 +266,8 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   };
 
   // issue the loads of plane q: the own site's 38 populations and, when the ring of that plane comes from frames, its pieces
-  auto pull_plane = [&](int q, double (&f)[Q], double (&g)[Q], double (&hv)[2][4], const int which = 0) {
+  // which: 0 both fluids, 1 the f half (with the frame pieces), 2 the g half; parts: 1 the own site's loads, 2 the frame pieces
+  auto pull_plane = [&](int q, double (&f)[Q], double (&g)[Q], double (&hv)[2][4], const int which = 0, const int parts = 3) {
     const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
                                          S + (long long)wrapp(q + 1) * G.plane };
     unsigned oo[3][3];
@@ -257,14 +275,16 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int b2 = 0; b2 < 3; ++b2) { oo[a][b2] = yo[a] + xo[b2]; asm volatile("" : "+v"(oo[a][b2])); }
+    if (parts & 1) {
 #pragma unroll
-    for (int i = 0; i < Q; ++i) {
-      const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
-      const unsigned o = oo[1 - Vel::cy[i]][1 + BFLBM_PX(Vel::cx[i])];
-      if (which != 2) f[i] = ld(b, o);
-      if (which != 1) g[i] = ld(b + (long long)Q * G.vol, o);
+      for (int i = 0; i < Q; ++i) {
+        const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
+        const unsigned o = oo[1 - Vel::cy[i]][1 + BFLBM_PX(Vel::cx[i])];
+        if (which != 2) f[i] = ld(b, o);
+        if (which != 1) g[i] = ld(b + (long long)Q * G.vol, o);
+      }
     }
-    if (which != 2 && Hg.use_frames && q >= fa && q <= fb && has_rtask) {
+    if ((parts & 2) && which != 2 && Hg.use_frames && q >= fa && q <= fb && has_rtask) {
       const double* __restrict__ fp = Hg.fin + (long long)q * Hg.fplane;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -290,6 +310,12 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   // vmcnt(0): the join with the paths that end in loads).
   auto position = [&](const int q, auto col_c, auto ldn_c) {
     constexpr bool do_collide = decltype(col_c)::value, load_next = decltype(ldn_c)::value;
+    // quiet kernel: the own loads of the f half are spread over the relaxation of f (below); the noise kernel keeps the burst
+    constexpr bool spread_f = do_collide && load_next && MODE == 0 && BFLBM_HO_SPREAD_F > 0;
+#ifdef BFLBM_STAMP
+    unsigned long long ts[HO_NSTAMP] = {0};
+#endif
+    HO_STAMP(0);                                             // top of the position
     const int slot = it & 3;
     const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
                                          S + (long long)wrapp(q + 1) * G.plane };
@@ -345,7 +371,9 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
         rp[slot][1][ry * LW + rx] = density(t[1]);
       }
     }
+    HO_STAMP(1);                                             // plane q arrived, densities summed
     __syncthreads();
+    HO_STAMP(2);                                             // barrier passed
     // frames of plane q-3: finished at the previous position, combined across rows now
     finish(q - 3, (it & 1) ^ 1);
     // 3. collide plane q-1
@@ -370,8 +398,10 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     for (int i = 0; i < Q; ++i) gl[i][tid] = cg[i];
 #pragma unroll
     for (int i = 0; i < Q; ++i) fl[i][tid] = cf[i];
+    HO_STAMP(3);                                             // frames finished, held plane read as moments, new plane parked in LDS
     // the f half of the next plane: in flight while plane q-1 is collided
-    if (load_next) pull_plane(q + 1, nf, ng, hvn, 1);
+    if (load_next) pull_plane(q + 1, nf, ng, hvn, 1, spread_f ? 2 : 3);
+    HO_STAMP(4);                                             // f half of plane q+1 requested
     if (do_collide) {
       const int sl[3] = { (it - 2) & 3, (it - 1) & 3, it & 3 };
       const double r = rp[sl[1]][0][lown], ph = rp[sl[1]][1][lown];
@@ -488,13 +518,39 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
           }
         }
       };
+      HO_STAMP(5);                                           // gradient, noise head, projection done
+      // Round 3 (tools/ho_stamps.py): a lone wave that issues its 19 requests as one burst stands at the issue for 2400 of
+      // the 18500 clocks of a position -- the burst is longer than the CU's request queue, and an in-order wave cannot
+      // compute while it waits for queue space.  In the quiet kernel the 19 own loads of the f half are therefore requested
+      // one every BFLBM_HO_SPREAD_F (30) VALU instructions of the relaxation of f; the order is pinned with
+      // sched_group_barrier (the compiler hoists independent loads to the top of the block otherwise).  512^3: 7817 ->
+      // 8484 and 8250 -> 8442 MLUPS on two boxes, 256^3 +2.5 %; spacings of 20 and 36, all 38 loads spread, and the
+      // noise kernel with any spacing were slower than the burst.
+      if (spread_f) pull_plane(q + 1, nf, ng, hvn, 1, 1);
       if (MODE == 1) d_relax_generated(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn3, NA.sr, ntab, rst, R.cs4);
       else           d_relax<false>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, zn, R.cs4);
+      if (spread_f) {
+#pragma unroll
+        for (int s_ = 0; s_ < Q; ++s_) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                      // one vector-memory read,
+          __builtin_amdgcn_sched_group_barrier(0x002, BFLBM_HO_SPREAD_F, 0);      // then this many VALU instructions
+        }
+      }
+      HO_STAMP(6);                                           // fluid f relaxed
       finish_fluid(mf, 0);
       if (load_next) pull_plane(q + 1, nf, ng, hvn, 2);       // the g half of the next plane: spreads the requests over the march position (+2.9 % at 512^3)
+      HO_STAMP(7);                                           // f stored, frames produced, g half requested
       if (MODE == 1) d_relax_generated(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn3, NA.sp, ntab, rst, R.cs4);
       else           d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
+      HO_STAMP(8);                                           // fluid g relaxed
       finish_fluid(mg, 1);
+      HO_STAMP(9);                                           // g stored
+#ifdef BFLBM_STAMP
+      if (blockIdx.x == 777 && it >= 40 && it < 40 + HO_STAMP_POS && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < HO_NSTAMP; ++k) g_ho_stamps[((it - 40) * 4 + ty) * HO_NSTAMP + k] = ts[k];
+      }
+#endif
     } else if (load_next) {
       // the first two positions of a chunk collide nothing: the g half goes now, and is waited for here (as in
       // the prologue: keeps vmcnt(0) out of the loop head)
