@@ -51,9 +51,6 @@
 #ifndef BFLBM_HO_SPREAD_F
 #define BFLBM_HO_SPREAD_F 30
 #endif
-#ifndef BFLBM_HO_TICK_EVERY
-#define BFLBM_HO_TICK_EVERY 2
-#endif
 
 // Diagnostic build (-DBFLBM_STAMP, tools/ho_stamps.py): shader-clock stamps at the phase boundaries of a march position,
 // written by lane 0 of every wave of ONE workgroup for 64 steady-state positions.  Not compiled into the product.
@@ -270,17 +267,14 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
 
   // issue the loads of plane q: the own site's 38 populations and, when the ring of that plane comes from frames, its pieces
   // which: 0 both fluids, 1 the f half (with the frame pieces), 2 the g half; parts: 1 the own site's loads, 2 the frame pieces
-  auto make_offsets = [&](unsigned (&oo)[3][3]) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b2 = 0; b2 < 3; ++b2) { oo[a][b2] = yo[a] + xo[b2]; asm volatile("" : "+v"(oo[a][b2])); }
-  };
   auto pull_plane = [&](int q, double (&f)[Q], double (&g)[Q], double (&hv)[2][4], const int which = 0, const int parts = 3) {
     const double* __restrict__ pl[3] = { S + (long long)wrapp(q - 1) * G.plane, S + (long long)wrapp(q) * G.plane,
                                          S + (long long)wrapp(q + 1) * G.plane };
     unsigned oo[3][3];
-    make_offsets(oo);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < 3; ++b2) { oo[a][b2] = yo[a] + xo[b2]; asm volatile("" : "+v"(oo[a][b2])); }
     if (parts & 1) {
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
@@ -544,27 +538,10 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       }
       HO_STAMP(6);                                           // fluid f relaxed
       finish_fluid(mf, 0);
-#ifdef BFLBM_HO_TICK_G
-      constexpr bool tick_g = spread_f;                      // experiment: the g half requested on the ticks of relax g
-#else
-      constexpr bool tick_g = false;
-#endif
-      if (load_next && !tick_g) pull_plane(q + 1, nf, ng, hvn, 2);       // the g half of the next plane: spreads the requests over the march position (+2.9 % at 512^3)
+      if (load_next) pull_plane(q + 1, nf, ng, hvn, 2);       // the g half of the next plane: spreads the requests over the march position (+2.9 % at 512^3)
       HO_STAMP(7);                                           // f stored, frames produced, g half requested
-      unsigned oog[3][3];
-      if (tick_g) make_offsets(oog);
-      const double* __restrict__ plg[3] = { S + (long long)wrapp(q) * G.plane, S + (long long)wrapp(q + 1) * G.plane, S + (long long)wrapp(q + 2) * G.plane };
-      auto tick_fn = [&](int t, double v) {
-        if (tick_g && (t % BFLBM_HO_TICK_EVERY) == 0 && t / BFLBM_HO_TICK_EVERY < Q) {
-          const int i = t / BFLBM_HO_TICK_EVERY;
-          const double* __restrict__ b = plg[1 - Vel::cz[i]] + (long long)(i + Q) * G.vol;
-          unsigned o = oog[1 - Vel::cy[i]][1 + BFLBM_PX(Vel::cx[i])];
-          asm volatile("" : "+v"(o) : "v"(__double2loint(v)));
-          ng[i] = ld(b, o);
-        }
-      };
       if (MODE == 1) d_relax_generated(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, gn3, NA.sp, ntab, rst, R.cs4);
-      else           d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4, tick_fn);
+      else           d_relax<false>(P, mg, ph, v_b, Hy.ug, Hy.ag, P.inv_tau_g_bar, zn, R.cs4);
       HO_STAMP(8);                                           // fluid g relaxed
       finish_fluid(mg, 1);
       HO_STAMP(9);                                           // g stored

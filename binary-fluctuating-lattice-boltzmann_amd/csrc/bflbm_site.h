@@ -407,39 +407,31 @@ __device__ __forceinline__ void d_force_moments(const DevParams& P, double rho, 
 // velocity v_b (equilibrium), its own real velocity u and acceleration a (force moments).
 // The noise of mode k is asked from `noise(k)` in mode order right where it is added (a generated stream never
 // exists as an array of 19 doubles); NOISE=false drops the terms (they are exactly +-0 when kBT == 0).
-// `tick(t, value)` is told when 39 values of the relaxation exist (t = 0..9 mEq, 10..19 mPhi, 20..38 the relaxed
-// moments): a kernel that wants memory instructions BETWEEN this arithmetic hangs them on these values (the compiler
-// otherwise hoists independent loads to the top of the block); the default does nothing.
-struct NoTick { __device__ __forceinline__ void operator()(int, double) const {} };
-template <bool NOISE, typename NoiseFn, typename Tick = NoTick>
+template <bool NOISE, typename NoiseFn>
 __device__ __forceinline__ void d_relax_with(const DevParams& P, double (&m)[Q], double rho_k, const double (&v_b)[3],
                                              const double (&u)[3], const double (&a)[3], double inv_tau_bar,
-                                             NoiseFn noise, double ycs4, Tick tick = Tick()) {
+                                             NoiseFn noise, double ycs4) {
   double mEq[10], mPhi[10];
   d_equilibrium(P, rho_k, v_b, mEq, ycs4);
   d_force_moments(P, rho_k, u, a, mPhi, ycs4);
-#pragma unroll
-  for (int k = 0; k < 10; ++k) { tick(k, mEq[k]); tick(10 + k, mPhi[k]); }
 #pragma unroll
   for (int k = 0; k < 10; ++k) {
     double R = inv_tau_bar*(mEq[k] - m[k]) + mPhi[k];
     if (NOISE) R = R + noise(k);
     m[k] = m[k] + R;
-    tick(20 + k, m[k]);
   }
 #pragma unroll
   for (int k = 10; k < Q; ++k) {
     double R = inv_tau_bar*(0. - m[k]) + 0.;
     if (NOISE) R = R + noise(k);
     m[k] = m[k] + R;
-    tick(20 + k, m[k]);
   }
 }
-template <bool NOISE, typename Tick = NoTick>
+template <bool NOISE>
 __device__ __forceinline__ void d_relax(const DevParams& P, double (&m)[Q], double rho_k, const double (&v_b)[3],
                                         const double (&u)[3], const double (&a)[3], double inv_tau_bar,
-                                        const double (&noise)[Q], double ycs4, Tick tick = Tick()) {
-  d_relax_with<NOISE>(P, m, rho_k, v_b, u, a, inv_tau_bar, [&](int k) { return noise[k]; }, ycs4, tick);
+                                        const double (&noise)[Q], double ycs4) {
+  d_relax_with<NOISE>(P, m, rho_k, v_b, u, a, inv_tau_bar, [&](int k) { return noise[k]; }, ycs4);
 }
 // relaxation of one fluid with the generated stream: n3 = its momentum-mode noise (fn3 or -fn3), s = A.sr / A.sp.
 // The fluid's 15 normals are drawn first as binary32 (their 15 table look-ups are in flight together), the
