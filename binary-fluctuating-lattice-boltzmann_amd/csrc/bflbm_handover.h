@@ -51,6 +51,9 @@
 #ifndef BFLBM_HO_SPREAD_F
 #define BFLBM_HO_SPREAD_F 30
 #endif
+#ifndef BFLBM_HO_SPREAD_F1
+#define BFLBM_HO_SPREAD_F1 0      // the noise kernel keeps the burst: spacings of 12 ... 60 were all slower
+#endif
 
 // Diagnostic build (-DBFLBM_STAMP, tools/ho_stamps.py): shader-clock stamps at the phase boundaries of a march position,
 // written by lane 0 of every wave of ONE workgroup for 64 steady-state positions.  Not compiled into the product.
@@ -311,7 +314,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   auto position = [&](const int q, auto col_c, auto ldn_c) {
     constexpr bool do_collide = decltype(col_c)::value, load_next = decltype(ldn_c)::value;
     // quiet kernel: the own loads of the f half are spread over the relaxation of f (below); the noise kernel keeps the burst
-    constexpr bool spread_f = do_collide && load_next && MODE == 0 && BFLBM_HO_SPREAD_F > 0;
+    constexpr bool spread_f = do_collide && load_next && (MODE == 0 ? BFLBM_HO_SPREAD_F > 0 : BFLBM_HO_SPREAD_F1 > 0);
 #ifdef BFLBM_STAMP
     unsigned long long ts[HO_NSTAMP] = {0};
 #endif
@@ -533,7 +536,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
 #pragma unroll
         for (int s_ = 0; s_ < Q; ++s_) {
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                      // one vector-memory read,
-          __builtin_amdgcn_sched_group_barrier(0x002, BFLBM_HO_SPREAD_F, 0);      // then this many VALU instructions
+          __builtin_amdgcn_sched_group_barrier(0x002, MODE == 0 ? BFLBM_HO_SPREAD_F : BFLBM_HO_SPREAD_F1, 0);      // then this many VALU instructions
         }
       }
       HO_STAMP(6);                                           // fluid f relaxed
