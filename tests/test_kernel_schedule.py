@@ -59,3 +59,23 @@ def test_handover_kernel_schedule(device_asm, mode):
     assert head and min(head) >= 19, f"loop head drains the stores again: {head}"
     # the pulled ring of the chunk-boundary planes is one batch: its waits count down once, so vmcnt(0) appears once
     assert sum(1 for _, w in waits if w == 0) <= 1, [w for _, w in waits]
+
+
+def test_quiet_kernel_requests_the_f_half_between_the_arithmetic(device_asm):
+    """Round 3: a lone wave that issues 19 requests back to back stands at the issue for as long as
+    the request queue takes to make room; the quiet kernel therefore requests the f half of the next plane one load every
+    30 VALU instructions of the relaxation (sched_group_barrier).  Left to itself the compiler hoists the loads into one
+    burst again, so the spacing is pinned here: at least 15 loads of the steady-state loop are followed by 20 or more VALU
+    instructions before the next vector-memory instruction."""
+    body, _ = _kernel(device_asm, 0)
+    lo, hi = _steady_loop(body)
+    spaced, gap, pending = 0, 0, False
+    for l in body[lo:hi]:
+        t = l.split()[0] if l.split() else ""
+        if t.startswith("global_load") or t.startswith("global_store"):
+            if pending and gap >= 20:
+                spaced += 1
+            pending, gap = t.startswith("global_load"), 0
+        elif t.startswith("v_"):
+            gap += 1
+    assert spaced >= 15, f"only {spaced} loads of the steady-state loop stand alone between arithmetic"
