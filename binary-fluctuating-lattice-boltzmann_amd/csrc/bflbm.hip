@@ -232,12 +232,28 @@ inline bool handover_contract_params(const bflbm_params& p) {
 inline bool handover_worthwhile(const bflbm_ctx* c, bool noisy) {
   static const int min_lz = [] { const char* e = getenv("BFLBM_AUTO_MIN_LZ"); return e ? atoi(e) : 16; }();
   const int lo = c->G.H, hi = c->G.H + c->nzl;
+  const int a = c->G.zwrap ? lo : lo + 2, b = c->G.zwrap ? hi : hi - 2;   // the interior sweep
+  if (b - a < min_lz || b - a < 4) return false;
   FusedGrid F;
-  handover_plan(c->G, c->G.zwrap ? lo : lo + 2, c->G.zwrap ? hi : hi - 2, 0, F);
+  handover_plan(c->G, a, b, 0, F);
   if (F.lz < min_lz) return false;
   if (noisy) return true;
   const double lanes_busy = (double)c->G.nx / (64.0 * F.ntx);
   return lanes_busy >= 0.77;
+}
+
+// Which bit-exact schedule `auto` takes at zero noise.  The one-pass kernel needs a workgroup per CU to be worth its two
+// planes of look-ahead per chunk: a lattice whose tile columns x 2-plane chunks do not fill the device runs the two-pass
+// schedule faster (same doubles): 32^3 2440 against 1000 MLUPS, 48^3 5070 / 3350, the reference's 8 x 256 x 64 flat-interface
+// box 5910 / 3530; 64^3 (exactly 256 workgroups) and 96^3 are equal (tools/size_sweep.sh).
+inline int exact_quiet_schedule(const bflbm_ctx* c) {
+  const int lo = c->G.H, hi = c->G.H + c->nzl;
+  const int a = c->G.zwrap ? lo : lo + 2, b = c->G.zwrap ? hi : hi - 2;   // the interior sweep
+  if (b - a < 2) return 0;                       // a slab of 4 or 5 planes is all boundary pairs
+  FusedGrid F;
+  (void)fused_plan(c->G, a, b, 0, 0, F);
+  const int ncu = g_fused_ncu > 0 ? g_fused_ncu : 256;
+  return F.total < ncu ? 0 : 1;
 }
 
 // 0 two-pass, 1 fused (pulled ring), 3 hand-over.  The bit-exact choice is 1 at zero noise and 0 with noise.
@@ -252,8 +268,9 @@ inline int resolved_schedule(const bflbm_ctx* c) {
   if (c->schedule != 2) return c->schedule;
   static const int auto_noise_fused = [] { const char* e = getenv("BFLBM_AUTO_NOISE_HANDOVER"); return e ? atoi(e) != 0 : true; }();
   static const int auto_exact = [] { const char* e = getenv("BFLBM_AUTO_EXACT"); return e && atoi(e) != 0; }();
-  if (auto_exact || c->inject || c->frames_unavailable || !handover_ok(c->G) || !handover_contract_params(c->prm)) return exact;
-  if (!handover_worthwhile(c, noisy)) return exact;
+  const int auto_exact_choice = noisy ? 0 : exact_quiet_schedule(c);
+  if (auto_exact || c->inject || c->frames_unavailable || !handover_ok(c->G) || !handover_contract_params(c->prm)) return auto_exact_choice;
+  if (!handover_worthwhile(c, noisy)) return auto_exact_choice;
   if (noisy && !auto_noise_fused) return 0;
   return 3;
 }

@@ -305,17 +305,15 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
 #endif
 
 static int g_fused_ncu = 0;     // compute units of the device (set at context creation)
-// returns non-zero on launch failure
-static inline int fused_launch(const double* S, double* D, const double* injf, const double* injg,
-                               const Geo& G, const DevParams& P, int pa, int pb,
-                               uint32_t noise_index, int mode, hipStream_t stream, int pair_len = 0) {
+// Tile shape, chunking and workgroup order of one launch of the fused kernel over the storage planes [pa, pb); returns the
+// tile width (the height is 512 / width)
+static inline int fused_plan(const Geo& G, int pa, int pb, int mode, int pair_len, FusedGrid& F) {
   // pair_len > 0: ONE launch over the two disjoint plane ranges [pa, pa+pair_len) and [pb-pair_len, pb)
   // (the boundary plane pairs of a slab), one chunk each.
   // Tile shape: 64 x 8 sites; lattices narrower than 64 in x get the same 512 sites as 32 x 16, 16 x 32 or 8 x 64
   // (zero noise only; e.g. the reference's 8 x 256 x 64 flat-interface box would use 8 of 64 lanes of a 64-wide tile)
   const int TX = (mode != 0 || G.nx > 32) ? BFLBM_FUSED_TX : (G.nx > 16 ? 32 : (G.nx > 8 ? 16 : 8));
   const int TY = (BFLBM_FUSED_TX * BFLBM_FUSED_TY) / TX;
-  FusedGrid F;
   F.ntx = (G.nx + TX - 1) / TX;
   F.nty = (G.ny + TY - 1) / TY;
   F.ncols = F.ntx * F.nty;
@@ -358,6 +356,16 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   F.total = F.ncols * F.nchunks;
   F.per_xcd = (F.total + 7) / 8;
   { static const int sx_env = [] { const char* e = getenv("BFLBM_MAP_SX"); return e ? atoi(e) : 0; }(); F.sx = sx_env > 0 ? sx_env : std::min(F.ntx, 4); }   // strips of 4 tiles: +2 % at 512^3 (ntx = 8), identical at 256^3
+  return TX;
+}
+
+// returns non-zero on launch failure
+static inline int fused_launch(const double* S, double* D, const double* injf, const double* injg,
+                               const Geo& G, const DevParams& P, int pa, int pb,
+                               uint32_t noise_index, int mode, hipStream_t stream, int pair_len = 0) {
+  FusedGrid F;
+  const int TX = fused_plan(G, pa, pb, mode, pair_len, F);
+  const int TY = (BFLBM_FUSED_TX * BFLBM_FUSED_TY) / TX;
   dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
   constexpr int TX0 = BFLBM_FUSED_TX, TY0 = BFLBM_FUSED_TY;
   if (mode == 2)      hipLaunchKernelGGL((k_fused<TX0, TY0, 2>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);

@@ -284,3 +284,21 @@ def test_native_ring_per_plane_copy_fallback():
     for env in ({}, {"BFLBM_RING_COPY_FALLBACK": "1"}):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "EQUAL True" in out.stdout, (env, out.stdout[-500:], out.stderr[-1500:])
+
+
+@pytest.mark.parametrize("n,nslabs", [((64, 8, 12), 3), ((128, 8, 16), 4), ((64, 8, 13), 3)])
+def test_auto_on_slabs_that_are_all_boundary_planes(pkg, ob, n, nslabs):
+    """A ring whose slabs are 4-5 planes thick has an EMPTY interior sweep; `auto` plans the kernels' chunking to pick
+    a schedule and must not divide by that zero (it did, once: SIGFPE in round 3).  Default schedule, lattices wide
+    enough for the hand-over kernel to be considered; 3 steps equal the oracle bit for bit (auto resolves to an exact
+    schedule for such slabs)."""
+    r = pkg.RingLBM(*n, nslabs=nslabs)
+    r.LBM_init_droplet(0.45)
+    r.LBM_timestep(3)
+    f, g = r.populations()
+    r.close()
+    ref = ob.OracleLattice(*n)
+    ref.init_droplet(0.45)
+    for _ in range(3):
+        ref.timestep()
+    assert np.array_equal(f, ref.f) and np.array_equal(g, ref.g)
