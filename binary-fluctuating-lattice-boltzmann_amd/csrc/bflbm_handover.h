@@ -49,7 +49,7 @@
 // Requests of the next plane's f half (quiet kernel): one every BFLBM_HO_SPREAD_F VALU instructions of the relaxation of
 // fluid f instead of one burst of 19 before it; 0 = burst (see the comment at the call site)
 #ifndef BFLBM_HO_SPREAD_F
-#define BFLBM_HO_SPREAD_F 30
+#define BFLBM_HO_SPREAD_F 28
 #endif
 #ifndef BFLBM_HO_SPREAD_F1
 #define BFLBM_HO_SPREAD_F1 0      // the noise kernel keeps the burst: spacings of 12 ... 60 were all slower
@@ -525,7 +525,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       // Round 3 (tools/ho_stamps.py): a lone wave that issues its 19 requests as one burst stands at the issue for 2400 of
       // the 18500 clocks of a position -- the burst is longer than the CU's request queue, and an in-order wave cannot
       // compute while it waits for queue space.  In the quiet kernel the 19 own loads of the f half are therefore requested
-      // one every BFLBM_HO_SPREAD_F (30) VALU instructions of the relaxation of f; the order is pinned with
+      // one every BFLBM_HO_SPREAD_F (28) VALU instructions of the relaxation of f; the order is pinned with
       // sched_group_barrier (the compiler hoists independent loads to the top of the block otherwise).  512^3: 7817 ->
       // 8484 and 8250 -> 8442 MLUPS on two boxes, 256^3 +2.5 %; spacings of 20 and 36, all 38 loads spread, and the
       // noise kernel with any spacing were slower than the burst.
