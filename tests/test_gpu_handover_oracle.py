@@ -249,18 +249,19 @@ def test_named_stress_cases(pkg, ob, threads, shape, frac, steps, par):
 
 
 def test_seeded_stress_draws(pkg):
-    """tools/ho_stress.py on two seeds (lattices up to 320 wide, every init, parameter draws that include diverging
-    ones, 1-3 slabs): no case where schedule 3 is outside the tolerance while the oracle's own one-ulp response is
+    """tools/ho_stress.py on four seeds (lattices up to 320 wide, two of the seeds on lattices that are not whole tiles --
+    widths 64 ... 300, heights 6 ... 43 --, every init, parameter draws that include diverging ones, 1-3 slabs): no case where schedule 3 is outside the tolerance while the oracle's own one-ulp response is
     inside it by a factor of ten, and the bit-exact schedule equals the oracle wherever the run stays finite."""
     import ho_stress
     import oracle_binding
     oracle_binding.lib().orc_set_threads(16)
     try:
         fails = 0
-        for seed in (11, 12):
+        for seed, ragged in ((11, False), (12, False), (13, True), (14, True)):
             rng = np.random.default_rng(seed)
             for case in range(8):
-                shape, init, par, steps, nslabs = ho_stress.draw(rng, [128, 192, 256, 320])
+                widths = [64, 66, 100, 130, 192, 250, 300] if ragged else [128, 192, 256, 320]
+                shape, init, par, steps, nslabs = ho_stress.draw(rng, widths, ragged)
                 fails += ho_stress.one_case(pkg, f"s{seed}c{case}", shape, init, par, steps, nslabs)
         assert fails == 0
     finally:

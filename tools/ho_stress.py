@@ -102,9 +102,9 @@ def one_case(pkg, tag, shape, init, par, steps, nslabs, trace=False, tol=1e-12):
     return bad
 
 
-def draw(rng, widths):
+def draw(rng, widths, ragged=False):
     nx = int(rng.choice(widths))
-    ny = int(rng.choice(np.arange(8, 44, 4)))
+    ny = int(rng.choice([v for v in range(6, 44) if v % 4 != 1])) if ragged else int(rng.choice(np.arange(8, 44, 4)))
     nz = int(rng.integers(4, 28))
     steps = int(rng.integers(3, 40))
     par = dict(alpha0=float(rng.choice([0.0, 1.5, 2.5, 4.0])), tau_f=float(rng.choice([0.5, 0.8, 1.0])), tau_g=float(rng.choice([0.5, 0.6, 1.0])),
@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--named", action="store_true")
     ap.add_argument("--trace", action="store_true")
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--ragged", action="store_true", help="lattices that are not whole 64 x 4 tiles: widths 64 ... 300, any height but 1 mod 4")
     a = ap.parse_args()
     pkg = ge.load_package()
     ob.lib().orc_set_threads(a.threads)
@@ -137,7 +138,7 @@ def main():
     for seed in a.seeds:
         rng = np.random.default_rng(seed)
         for case in range(a.cases):
-            shape, init, par, steps, nslabs = draw(rng, [128, 192, 256, 320])
+            shape, init, par, steps, nslabs = draw(rng, [64, 66, 100, 130, 192, 250, 300] if a.ragged else [128, 192, 256, 320], a.ragged)
             fails += one_case(pkg, f"s{seed}c{case}", shape, init, par, steps, nslabs)
     print("failures:", fails)
     return 1 if fails else 0
