@@ -39,6 +39,12 @@ class Fab(ctypes.Structure):
                 ("vlo", ctypes.c_int * 3), ("vhi", ctypes.c_int * 3)]
 
 
+class FlowFitOpts(ctypes.Structure):
+    """bflbm_flowfit_opts (include/bflbm.h): options of the reference's gradient-flow radius fit."""
+    _fields_ = [(n, ctypes.c_double) for n in "W0 R0 eta_W eta_R dt undul_ratio".split()] + \
+               [(n, ctypes.c_int) for n in "nstep step_window max_retry".split()]
+
+
 # name -> (restype, argtypes); every symbol declared in include/bflbm.h
 _P = ctypes.POINTER
 _vp = ctypes.c_void_p
@@ -104,6 +110,10 @@ SIGNATURES = {
     "bflbm_ring_droplet_moments": (ctypes.c_int, [_vp, _dp]),
     "bflbm_fit_droplet": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_double, _dp, _P(ctypes.c_int)]),
     "bflbm_ring_fit_droplet": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_double, _dp, _P(ctypes.c_int)]),
+    "bflbm_flowfit_default_opts": (None, [_P(FlowFitOpts)]),
+    "bflbm_fit_droplet_flow": (ctypes.c_int, [_vp, _P(FlowFitOpts), _dp, _P(ctypes.c_int)]),
+    "bflbm_ring_fit_droplet_flow": (ctypes.c_int, [_vp, _P(FlowFitOpts), _dp, _P(ctypes.c_int)]),
+    "bflbm_flowfit_coefficients": (ctypes.c_int, [ctypes.c_double] * 6 + [_dp]),
     "bflbm_sf_create": (ctypes.c_int, [_vp, ctypes.c_int, _P(ctypes.c_int), _P(ctypes.c_int), _dp, _P(_vp)]),
     "bflbm_sf_destroy": (ctypes.c_int, [_vp]),
     "bflbm_sf_reset": (ctypes.c_int, [_vp]),

@@ -85,6 +85,24 @@ class _DropletMixin:
         self.last_fit = dict(cost=cost.value, iterations=it.value)
         return tuple(p)
 
+    def fit_droplet_flow(self, **opts):
+        """(W, R, undulation) of the reference's own gradient-flow fit (fittingDropletParams, LBM_hydrovs.H:160-213):
+        rho ~ 1/2 (1 + tanh((R - |r - r0|) / sqrt(2 W))) in unit-box coordinates.  Keyword options are the fields of
+        bflbm_flowfit_opts (W0, R0, eta_W, eta_R, dt, undul_ratio, nstep, step_window, max_retry); the driver's call is
+        fit_droplet_flow(step_window=20, undul_ratio=0.01, nstep=400, W0=kappa, R0=radius) (main_run_job.cpp:365).
+        Raises BflbmError where the reference throws (undulation out of bounds after the retries)."""
+        o = _lib.FlowFitOpts()
+        self.lib.bflbm_flowfit_default_opts(ctypes.byref(o))
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise AttributeError(f"unknown fit option {k!r}")
+            setattr(o, k, v)
+        res = (ctypes.c_double * 3)()
+        retries = ctypes.c_int()
+        check(getattr(self.lib, self._droplet_fn[2])(self._h, ctypes.byref(o), res, ctypes.byref(retries)))
+        self.last_fit = dict(retries=retries.value)
+        return tuple(res)
+
 
 # kernel schedules of include/bflbm.h (bflbm_set_schedule): "fused" = plane march with the ring densities pulled
 # (bit-exact), "handover" = plane march with the ring densities handed over from the previous step (tolerance)
@@ -92,7 +110,7 @@ SCHEDULES = {"two_pass": 0, "fused": 1, "fused_exact": 1, "auto": 2, "handover":
 
 
 class BinaryLBM(_DropletMixin):
-    _droplet_fn = ("bflbm_droplet_moments", "bflbm_fit_droplet")
+    _droplet_fn = ("bflbm_droplet_moments", "bflbm_fit_droplet", "bflbm_fit_droplet_flow")
 
     """One z-slab [z0, z1) of a periodic nx*ny*nz D3Q19 binary-fluid lattice on one GPU."""
 
@@ -374,7 +392,7 @@ class BinaryLBM(_DropletMixin):
 
 
 class RingLBM(_DropletMixin):
-    _droplet_fn = ("bflbm_ring_droplet_moments", "bflbm_ring_fit_droplet")
+    _droplet_fn = ("bflbm_ring_droplet_moments", "bflbm_ring_fit_droplet", "bflbm_ring_fit_droplet_flow")
 
     """The whole lattice as a ring of z-slabs driven by this one process through the native ring of the
     C-ABI (bflbm_ring_*): slab r on GPU devices[r % len(devices)], halo exchange by peer copies overlapped

@@ -284,6 +284,28 @@ int bflbm_ring_droplet_moments(bflbm_ring* r, double moments[20]);
 int bflbm_fit_droplet(bflbm_ctx* c, const double r0[3], double params[4], int max_iter, double tol, double* cost, int* iterations);
 int bflbm_ring_fit_droplet(bflbm_ring* r, const double r0[3], double params[4], int max_iter, double tol, double* cost, int* iterations);
 
+/* The reference's own radius fit (fittingDropletParams, LBM_hydrovs.H:160-213; call site main_run_job.cpp:364-367, off by
+ * default: `if_print_radius = false`, :111): a semi-implicit gradient flow of (W, R) in
+ * rho ~ 1/2 (1 + tanh((R - |r - r0|) / sqrt(2W))), unit-box coordinates, r0 = centre of mass of rho; `nstep` flow steps
+ * from (W0, R0), the result is the mean over the last `step_window` steps, retried from that mean with dt / 5 (at most
+ * `max_retry` times) while (max - min) / mean over the window exceeds `undul_ratio` for either parameter.  The two lattice
+ * integrals of every step are reduced on the device; the closed-form coefficients (externlib.H:199-371) on the host.
+ * result = { W, R, undulation }.  Returns non-zero (message in bflbm_last_error) where the reference throws: undulation still
+ * out of bounds after the retries; result is filled nevertheless.  opts == NULL: the reference's default arguments
+ * (W0 0.02, R0 0.3, eta 0.2, dt 0.02, 400 steps, window 30, undulation 0.005); the driver passes
+ * (window 20, undulation 0.01, 400 steps, W0 = kappa, R0 = radius).  No output of this fit is recorded in the reference:
+ * parity unpinned. */
+typedef struct {
+  double W0, R0, eta_W, eta_R, dt, undul_ratio;
+  int nstep, step_window, max_retry;
+} bflbm_flowfit_opts;
+void bflbm_flowfit_default_opts(bflbm_flowfit_opts* o);
+int bflbm_fit_droplet_flow(bflbm_ctx* c, const bflbm_flowfit_opts* opts, double result[3], int* retries);
+int bflbm_ring_fit_droplet_flow(bflbm_ring* r, const bflbm_flowfit_opts* opts, double result[3], int* retries);
+/* Host only: the closed forms of one flow step at (W, R) -- out = { J_RR, J_WR, J_RW, J_WW, K_W, K_R, I_2, I_3, I_4 }
+ * with I_n = int_{-c}^{inf} (x + c)^n sech^4(x) dx, c = R / sqrt(2W) (externlib.H:108-157, :199-253, :344-371). */
+int bflbm_flowfit_coefficients(double W, double R, double eta_W, double eta_R, double dt, double C0, double out[9]);
+
 /* hipEvent timing on the context's stream: start, run steps, stop -> milliseconds. */
 int bflbm_timer_start(bflbm_ctx* c);
 int bflbm_timer_stop(bflbm_ctx* c, float* ms);
