@@ -143,6 +143,13 @@ int main(int argc, char* argv[]) {
     structFact.WritePlotFile(nsteps, (double)nsteps, plot_root + "/plt_SF", 1);                           // :50-54
     std::printf("sf_samples %lld\n", structFact.nsamples());
   }
+  // if_print_radius (:111, :364-367): the reference's own radius fit of rho, here on the resident state
+  if (std::getenv("LBM_PRINT_RADIUS") && system == "droplet") {
+    const double W0 = std::getenv("LBM_RADIUS_W0") ? std::atof(std::getenv("LBM_RADIUS_W0")) : (double)kappa;   // the driver passes kappa, :365
+    const std::array<double, 3> param_arr = bflbm::fittingDropletParams(geom, 20, 0.01, 400, W0, 0.2);
+    std::printf("fitting parameters for equilibrium density rho: (W=%f, R=%f)\n", param_arr[0], param_arr[1]);
+    std::printf("radius_fit %.17g %.17g %.3e\n", param_arr[0], param_arr[1], param_arr[2]);
+  }
   // restart path of the live driver (:253-270): continue from the populations just produced
   if (std::getenv("LBM_RESTART_CHECK") && std::atoi(std::getenv("LBM_RESTART_CHECK")) != 0) {
     MultiFab f_last(ba, nvel, nghost, domain), g_last(ba, nvel, nghost, domain);

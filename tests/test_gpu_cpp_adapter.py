@@ -248,3 +248,18 @@ def test_cpp_structfact_on_a_decomposed_lattice(pkg, tmp_path):
         assert a.shape == b.shape
         scale = np.abs(a).reshape(a.shape[0], -1).max(axis=1)[:, None, None, None] + 1e-300
         assert np.all(np.abs(a - b) <= 1e-11 * scale)
+
+
+def test_cpp_driver_prints_the_fitted_radius(pkg):
+    """if_print_radius (main_run_job.cpp:111, :364-367): `bflbm::fittingDropletParams(geom, 20, 0.01, 400, W0, radius)` --
+    the reference's argument list -- on the resident rho of a 32^3 droplet after 300 steps equals the python call on the
+    same state, and prints the reference's line.  (W0 from LBM_RADIUS_W0: the driver's own W0 = kappa = 4 starts the flow
+    where the closed forms of the reference are outside their range, c = R / sqrt(2W) < 1.)"""
+    o = _run_env({"LBM_PRINT_RADIUS": 1, "LBM_RADIUS_W0": 0.004, "BFLBM_AUTO_EXACT": 1}, 32, 300, "droplet", 0, 2.5, 2)
+    W, R = float(o["radius_fit"][0]), float(o["radius_fit"][1])
+    assert o["fitting"][:5] == ["parameters", "for", "equilibrium", "density", "rho:"]
+    with pkg.BinaryLBM(32, 32, 32, params=pkg.default_params(alpha0=2.5), schedule="fused") as l:
+        l.LBM_init_droplet(0.2)
+        l.LBM_timestep(300)
+        Wp, Rp, _ = l.fit_droplet_flow(step_window=20, undul_ratio=0.01, nstep=400, W0=0.004, R0=0.2)
+    assert abs(W - Wp) <= 1e-12 * abs(Wp) and abs(R - Rp) <= 1e-12 * abs(Rp), (W, Wp, R, Rp)
