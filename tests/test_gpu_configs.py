@@ -199,3 +199,33 @@ def test_handover_random_cases(pkg):
             l.close()
         assert np.isfinite(out["handover"]).all(), (case, nx, ny, nz)
         _tolerances(out["handover"], out["fused"])
+
+
+def test_config4_spinodal_slabs_with_the_default_schedule(pkg):
+    """configs[4] as a user runs it: LBM_init_mixture is homogeneous (LBM_binary.H:613-614), so the "spinodal mixture" is
+    alpha0 = 4 with kBT = 1e-5 seeding the decomposition; two 1024 x 1024 x 64 slabs under `auto` (= the
+    hand-over kernel with the generator inside, in every slab's interior sweep and boundary pairs).  The noise stream is
+    a function of the GLOBAL site index, so the first step equals the undecomposed two-pass run bit for bit; after 8
+    steps the two agree at the north-star tolerance (metric of tests/tolerances.py); mass is conserved to rounding."""
+    import tolerances
+    nx, ny, nz = 1024, 1024, 128
+    par = pkg.default_params(kBT=1e-5, alpha0=4.0)
+    out = {}
+    for name, make in (("exact", lambda: pkg.BinaryLBM(nx, ny, nz, params=par, schedule="two_pass")),
+                       ("slabs", lambda: pkg.RingLBM(nx, ny, nz, nslabs=2, devices=(0,), params=par))):
+        l = make()
+        if name == "slabs":
+            assert l.slabs[0].resolved_schedule() == "handover"
+        l.LBM_init_mixture()
+        m0 = l.mass()
+        l.LBM_timestep(1)
+        h1 = l.LBM_hydrovars_density() if name == "exact" else l.LBM_hydrovars_density()
+        l.LBM_timestep(7)
+        out[name] = (h1, l.LBM_hydrovars(ncomp=9), m0, l.mass())
+        l.close()
+    assert np.array_equal(out["exact"][0], out["slabs"][0])                     # step 1: same normals at every site
+    tolerances.check(out["slabs"][1], out["exact"][1], "1024x1024x128 spinodal, 8 steps")
+    for name in out:
+        m0, m1 = out[name][2], out[name][3]
+        assert abs(m1[0] - m0[0]) <= 1e-12 * m0[0] and abs(m1[1] - m0[1]) <= 1e-12 * m0[1]
+    assert out["slabs"][1][0].std() > 1e-4                                       # the noise is there
