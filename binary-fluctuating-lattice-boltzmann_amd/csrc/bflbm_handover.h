@@ -375,16 +375,10 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       }
     }
     HO_STAMP(1);                                             // plane q arrived, densities summed
-#ifndef BFLBM_HO_EARLY_SWAP
-#define BFLBM_HO_EARLY_SWAP 0
-#endif
-    constexpr bool early_swap = BFLBM_HO_EARLY_SWAP && MODE == 1;   // experiment: hold swap and f requests BEFORE the barrier (they touch thread-private LDS columns only)
-    if (!early_swap) {
-      __syncthreads();
-      HO_STAMP(2);                                           // barrier passed
-      // frames of plane q-3: finished at the previous position, combined across rows now
-      finish(q - 3, (it & 1) ^ 1);
-    }
+    __syncthreads();
+    HO_STAMP(2);                                             // barrier passed
+    // frames of plane q-3: finished at the previous position, combined across rows now
+    finish(q - 3, (it & 1) ^ 1);
     // 3. collide plane q-1
     const int pc = q - 1;
     double mg[Q], jg[3];
@@ -411,10 +405,6 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
     // the f half of the next plane: in flight while plane q-1 is collided
     if (load_next) pull_plane(q + 1, nf, ng, hvn, 1, spread_f ? 2 : 3);
     HO_STAMP(4);                                             // f half of plane q+1 requested
-    if (early_swap) {
-      __syncthreads();
-      finish(q - 3, (it & 1) ^ 1);
-    }
     if (do_collide) {
       const int sl[3] = { (it - 2) & 3, (it - 1) & 3, it & 3 };
       const double r = rp[sl[1]][0][lown], ph = rp[sl[1]][1][lown];
