@@ -533,6 +533,9 @@ static int run_init(bflbm_ctx* c, int mode, const double* rho_ext_host, size_t n
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->steps = 0; c->density_valid = false; c->step_open = false; c->com_valid = false;
   for (auto& b : c->fsig) for (auto& sg : b) sg = HoSig();     // the hand-over frames describe another state
+  // the frames of schedule 3 are allocated here, where a run starts, rather than inside its first (possibly timed or
+  // overlapped) step; a failure is remembered and `auto` stays bit-exact (an explicit schedule 3 reports it at the step)
+  if ((c->schedule == 2 || c->schedule == 3) && resolved_schedule(c) == 3) (void)ensure_frames(c, true);
   c->ref_kind = (mode == 0) ? 2 : 1;             // thermal_noise gets the absolute COM (:623-625) or zero (:690, :739)
   c->ref_kind_step = 0;
   return 0;
@@ -623,6 +626,7 @@ int bflbm_commit_upload(bflbm_ctx* c, int reset) {
   c->density_valid = false; c->step_open = false; c->com_valid = false;
   for (auto& b : c->fsig) for (auto& sg : b) sg = HoSig();
   c->ref_kind = 0; c->ref_kind_step = c->steps;  // LBM_init: COM relative to com_ref (:651-654)
+  if ((c->schedule == 2 || c->schedule == 3) && resolved_schedule(c) == 3) (void)ensure_frames(c, true);   // as after the analytic inits
   return 0;
 }
 
