@@ -95,11 +95,14 @@ int bflbm_set_stream(bflbm_ctx* c, void* hip_stream, int external);
  *   0  two-pass (density pass + collide pass); bit-exact; the only one that takes injected or reference-state noise
  *   1  fused plane-marching kernel, tile-ring densities pulled; bit-exact; zero noise or generated noise
  *   3  pipelined plane-marching kernel, tile-ring densities handed over from the previous step
- *      (csrc/bflbm_handover.h); zero noise or generated thermal noise (it draws the normals itself); needs a lattice
- *      of full 64 x 4 tiles with at least two tiles per direction and no injected noise, otherwise it resolves to the
- *      bit-exact schedule (1 at zero noise, 0 with noise).  Fails if its frames (5.6 % of the state) cannot be allocated.
- *   2  auto (default): 3 where it applies AND alpha0 (|rho_hi| + |rho_lo|) <= 6 AND the frames fit in device memory,
- *      else the bit-exact schedule.  BFLBM_AUTO_EXACT=1 in the environment keeps auto bit-exact, with and without noise.
+ *      (csrc/bflbm_handover.h); zero noise or generated thermal noise (it draws the normals itself); takes every lattice
+ *      with nx >= 64, ny >= 4, nx % 64 != 1, ny % 4 != 1 (a narrower last tile column and a lower last tile row are
+ *      handled) and no injected noise, otherwise it resolves to the bit-exact schedule (1 at zero noise, 0 with noise).
+ *      Fails if its frames (5.6 % of the state) cannot be allocated.
+ *   2  auto (default): 3 where it applies AND is the faster kernel (marches of >= 16 planes; at zero noise a last tile
+ *      column with >= 77 % of its lanes busy) AND alpha0 (|rho_hi| + |rho_lo|) <= 6 AND the frames fit in device memory;
+ *      else a bit-exact schedule: 0 with noise, and at zero noise 1, or 0 on lattices too small to give the one-pass kernel
+ *      a workgroup per CU.  BFLBM_AUTO_EXACT=1 in the environment keeps auto bit-exact, with and without noise.
  * Schedules 0 and 1 give the CPU reference's doubles (same operation order).  Schedule 3 adds the 19 populations of
  * a tile-ring density in another fixed order: deterministic, run-to-run reproducible, the first step after an init or
  * upload bit-identical, later steps different from the reference by what a one-ulp change of the state does.  Measured
