@@ -326,3 +326,30 @@ def test_restart_continues_the_noise_index(pkg):
         l.LBM_init(f7, g7); l.set_steps_done(7); l.LBM_timestep(5)
         again = l.populations()
     assert np.array_equal(again[0], straight[0]) and np.array_equal(again[1], straight[1])
+
+
+@pytest.mark.parametrize("shape,nslabs", [((128, 8, 9), 1), ((250, 10, 12), 1), ((192, 12, 26), 2)])
+def test_handover_from_uploaded_populations(pkg, ob, threads, shape, nslabs):
+    """LBM_init(f0, g0) (LBM_binary.H:632-661) with populations that no analytic init produces -- a droplet state with 1 %
+    multiplicative noise on every population -- then the hand-over schedule: the first step after the upload pulls its
+    ring (bit-exact), ten more stay inside the tolerance; whole tiles, a ragged lattice, a ring of slabs."""
+    par = dict(alpha0=2.0)
+    ref = ob.OracleLattice(*shape, params=ob.default_params(**par))
+    ref.init_droplet(droplet_radius(shape))
+    rng = np.random.default_rng(17)
+    f0 = np.ascontiguousarray(ref.f * (1 + 0.01 * rng.standard_normal(ref.f.shape)))
+    g0 = np.ascontiguousarray(ref.g * (1 + 0.01 * rng.standard_normal(ref.g.shape)))
+    ref.init_from(f0, g0)
+    lbm = _make(pkg, shape, par, nslabs)
+    lbm.LBM_init(f0, g0)
+    ref.timestep(); lbm.LBM_timestep(1)
+    f, g = lbm.populations()
+    assert np.array_equal(f, ref.f) and np.array_equal(g, ref.g)
+    for _ in range(10):
+        ref.timestep()
+    lbm.LBM_timestep(10)
+    f, g = lbm.populations()
+    assert not np.array_equal(f, ref.f)                      # the frames were in use
+    assert max(np.abs(f - ref.f).max(), np.abs(g - ref.g).max()) < 1e-13
+    _tolerances(lbm.LBM_hydrovars(), ref.h, f"{shape} uploaded")
+    lbm.close()
