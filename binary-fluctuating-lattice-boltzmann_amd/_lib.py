@@ -71,6 +71,11 @@ SIGNATURES = {
     "bflbm_step_count": (ctypes.c_int, [_vp, _P(ctypes.c_longlong)]),
     "bflbm_set_step_count": (ctypes.c_int, [_vp, ctypes.c_longlong]),
     "bflbm_ring_set_step_count": (ctypes.c_int, [_vp, ctypes.c_longlong]),
+    "bflbm_ring_set_overlap": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "bflbm_ring_set_transport": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "bflbm_ring_last_transport": (ctypes.c_int, [_vp, _P(ctypes.c_int), _P(ctypes.c_int)]),
+    "bflbm_state_total_max": (ctypes.c_int, [_vp, _dp]),
+    "bflbm_set_state_total_max": (ctypes.c_int, [_vp, ctypes.c_double]),
     "bflbm_step_boundary": (ctypes.c_int, [_vp]),
     "bflbm_step_interior": (ctypes.c_int, [_vp]),
     "bflbm_step_finish": (ctypes.c_int, [_vp]),

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -105,6 +106,7 @@ struct bflbm_ctx {
   bool frames_unavailable = false;          // their allocation failed once: auto stays on the bit-exact schedules
   HoSig fsig[2][2];              // [state buffer][0 interior sweep, 1 boundary pairs]: the launch that wrote the frames
   bool step_open = false;
+  double total_max = -1.;        // largest |rho + phi| of the state an upload made resident (< 0: analytic init, the parameters say it)
   bool density_valid = false;   // rho/phi arrays hold the densities of the resident state
   size_t bytes = 0;
   // USE_REF_STATE (LBM_binary.H:12, :92-107): noise amplitudes from an equilibrium state
@@ -199,15 +201,16 @@ int launch_handover(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
   if (pb <= pa) return 0;
   if (ensure_frames(c)) return 1;
   const int kind = pair_len > 0 ? 1 : 0;
-  return handover_launch(c->S[c->cur], c->S[1 - c->cur], c->frames[c->cur], c->frames[1 - c->cur], c->G, c->dp, pa, pb,
-                         c->steps, c->fsig[c->cur][kind], c->fsig[1 - c->cur][kind], c->stream, pair_len, c->dp.noise_on ? 1 : 0)
-             ? fail("hand-over launch failed: %s", hipGetErrorString(hipGetLastError())) : 0;
+  const hipError_t e = handover_launch(c->S[c->cur], c->S[1 - c->cur], c->frames[c->cur], c->frames[1 - c->cur], c->G, c->dp, pa, pb,
+                                       c->steps, c->fsig[c->cur][kind], c->fsig[1 - c->cur][kind], c->stream, pair_len, c->dp.noise_on ? 1 : 0);
+  return e != hipSuccess ? fail("hand-over launch failed: %s", hipGetErrorString(e)) : 0;
 }
 
 int launch_fused(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
   if (pb <= pa) return 0;
-  return fused_launch(c->S[c->cur], c->S[1 - c->cur], c->injf, c->injg, c->G, c->dp, pa, pb,
-                      (uint32_t)c->steps, c->inject ? 2 : (c->dp.noise_on ? 1 : 0), c->stream, pair_len) ? fail("fused launch failed: %s", hipGetErrorString(hipGetLastError())) : 0;
+  const hipError_t e = fused_launch(c->S[c->cur], c->S[1 - c->cur], c->injf, c->injg, c->G, c->dp, pa, pb,
+                                    (uint32_t)c->steps, c->inject ? 2 : (c->dp.noise_on ? 1 : 0), c->stream, pair_len);
+  return e != hipSuccess ? fail("fused launch failed: %s", hipGetErrorString(e)) : 0;
 }
 
 // The range of model parameters inside which `auto` uses the hand-over kernel.  Schedule 3 differs from the reference's
@@ -218,8 +221,14 @@ int launch_fused(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
 // (alpha0 = 4 with rho_hi = 3: NaN within 10-40 steps on the CPU path too).  Those diverging runs all have an
 // interaction strength alpha0 (rho_hi + rho_lo) >= 7.5; every parameter set the reference ships or its notebooks record
 // has <= 5.1 (header defaults 4 x 1, Surface_Tension.ipynb 1.5 x 3 and 1.7 x 3).  `auto` stays bit-exact above 6.
-inline bool handover_contract_params(const bflbm_params& p) {
-  return std::fabs(p.alpha0) * (std::fabs(p.rho_hi) + std::fabs(p.rho_lo)) <= 6.0;
+// rho_hi + rho_lo is the total density rho + phi of every site of an analytic init (LBM_binary.H:681, :731: phi =
+// rho_hi + rho_lo - rho).  After LBM_init(f0, g0) (:632-661, the restart path) the resident densities need not relate to
+// the parameters at all, so the bound is then taken on the state: the largest |rho + phi| the upload made resident
+// (reduced once in bflbm_commit_upload); a non-finite value keeps auto bit-exact.
+inline bool handover_contract_params(const bflbm_ctx* c) {
+  const bflbm_params& p = c->prm;
+  const double total = c->total_max >= 0. ? c->total_max : std::fabs(p.rho_hi) + std::fabs(p.rho_lo);
+  return std::fabs(p.alpha0) * total <= 6.0;       // false for NaN
 }
 
 // Where `auto` expects schedule 3 to be the faster one (A/B on MI355X, tools/ragged_ab.sh):
@@ -269,7 +278,7 @@ inline int resolved_schedule(const bflbm_ctx* c) {
   static const int auto_noise_fused = [] { const char* e = getenv("BFLBM_AUTO_NOISE_HANDOVER"); return e ? atoi(e) != 0 : true; }();
   static const int auto_exact = [] { const char* e = getenv("BFLBM_AUTO_EXACT"); return e && atoi(e) != 0; }();
   const int auto_exact_choice = noisy ? 0 : exact_quiet_schedule(c);
-  if (auto_exact || c->inject || c->frames_unavailable || !handover_ok(c->G) || !handover_contract_params(c->prm)) return auto_exact_choice;
+  if (auto_exact || c->inject || c->frames_unavailable || !handover_ok(c->G) || !handover_contract_params(c)) return auto_exact_choice;
   if (!handover_worthwhile(c, noisy)) return auto_exact_choice;
   if (noisy && !auto_noise_fused) return 0;
   return 3;
@@ -532,6 +541,7 @@ static int run_init(bflbm_ctx* c, int mode, const double* rho_ext_host, size_t n
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->steps = 0; c->density_valid = false; c->step_open = false; c->com_valid = false;
+  c->total_max = -1.;                              // rho + phi = rho_hi + rho_lo at every site
   for (auto& b : c->fsig) for (auto& sg : b) sg = HoSig();     // the hand-over frames describe another state
   // the frames of schedule 3 are allocated here, where a run starts, rather than inside its first (possibly timed or
   // overlapped) step; a failure is remembered and `auto` stays bit-exact (an explicit schedule 3 reports it at the step)
@@ -626,7 +636,34 @@ int bflbm_commit_upload(bflbm_ctx* c, int reset) {
   c->density_valid = false; c->step_open = false; c->com_valid = false;
   for (auto& b : c->fsig) for (auto& sg : b) sg = HoSig();
   c->ref_kind = 0; c->ref_kind_step = c->steps;  // LBM_init: COM relative to com_ref (:651-654)
+  // what `auto` keys its stability bound on from here on: the total density the upload made resident, not rho_hi/rho_lo
+  // (handover_contract_params).  The own planes' densities need no halo (the upload buffer holds the streamed populations
+  // of every own site), so the slab reduces its own maximum; a ring combines the slabs' (bflbm_ring_commit_upload).
+  {
+    const int lo = own_lo(c);
+    hipLaunchKernelGGL(k_density_streamed, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->S[1 - c->cur], c->rho, c->phi, c->G, lo);
+    hipLaunchKernelGGL(k_total_absmax, plane_grid(c, c->nzl), dim3(256), 0, c->stream, c->rho, c->phi, c->partial, c->G, lo);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> h(c->partial_n);
+    HIP_TRY(hipMemcpyAsync(h.data(), c->partial, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double m = 0.;
+    for (double v : h) m = (v != v || m != m) ? (m + v) : std::max(m, v);
+    c->total_max = (m == m) ? m : std::numeric_limits<double>::infinity();     // NaN in the upload: never schedule 3
+  }
   if ((c->schedule == 2 || c->schedule == 3) && resolved_schedule(c) == 3) (void)ensure_frames(c, true);   // as after the analytic inits
+  return 0;
+}
+
+// the total-density bound of `auto` (see handover_contract_params): < 0 = from the parameters
+int bflbm_state_total_max(const bflbm_ctx* c, double* total_max) {
+  if (!c || !total_max) return fail("null argument");
+  *total_max = c->total_max;
+  return 0;
+}
+int bflbm_set_state_total_max(bflbm_ctx* c, double total_max) {      // a driver that owns several slabs hands every slab the global maximum
+  if (!c) return fail("null context");
+  c->total_max = total_max;
   return 0;
 }
 
@@ -650,23 +687,25 @@ int bflbm_step_boundary(bflbm_ctx* c) {
   HIP_TRY(hipSetDevice(c->dom.device));
   if (prepare_ref(c)) return 1;
   if (c->schedule == 2 && resolved_schedule(c) == 3) (void)ensure_frames(c, true);   // auto: falls back when they do not fit
+  // an explicit schedule 3 whose frames cannot be allocated fails HERE, before the step is opened: nothing of the resident
+  // state has been touched and the caller may switch to an exact schedule and go on
+  if (c->schedule == 3 && resolved_schedule(c) == 3 && ensure_frames(c)) return 1;
   c->step_open = true;
   const int lo = own_lo(c), hi = own_hi(c);
   if (c->G.zwrap) return 0;                      // single slab: everything is "interior"
   const int sch = resolved_schedule(c);
+  int rc;
   if (sch == 3) {
-    if (hi - lo > 4) return launch_handover(c, lo, hi, 2);
-    if (launch_handover(c, lo, lo + 2, 2)) return 1;
-    return launch_handover(c, hi - 2, hi, 2);
+    if (hi - lo > 4) rc = launch_handover(c, lo, hi, 2);
+    else rc = launch_handover(c, lo, lo + 2, 2) || launch_handover(c, hi - 2, hi, 2);
+  } else if (sch == 1) {
+    if (hi - lo > 4) rc = launch_fused(c, lo, hi, 2);        // both boundary plane pairs in one launch
+    else rc = launch_fused(c, lo, lo + 2) || launch_fused(c, hi - 2, hi);
+  } else {
+    rc = ensure_density(c) || launch_collide(c, lo, lo + 2) || launch_collide(c, hi - 2, hi);
   }
-  if (sch == 1) {
-    if (hi - lo > 4) return launch_fused(c, lo, hi, 2);      // both boundary plane pairs in one launch
-    if (launch_fused(c, lo, lo + 2)) return 1;
-    return launch_fused(c, hi - 2, hi);
-  }
-  if (ensure_density(c)) return 1;
-  if (launch_collide(c, lo, lo + 2)) return 1;
-  return launch_collide(c, hi - 2, hi);
+  if (rc) c->step_open = false;                  // a failed launch wrote nothing that the resident state S[cur] holds
+  return rc;
 }
 
 int bflbm_step_interior(bflbm_ctx* c) {
@@ -676,10 +715,12 @@ int bflbm_step_interior(bflbm_ctx* c) {
   const int lo = own_lo(c), hi = own_hi(c);
   const int a = c->G.zwrap ? lo : lo + 2, b = c->G.zwrap ? hi : hi - 2;
   const int sch = resolved_schedule(c);
-  if (sch == 3) return launch_handover(c, a, b);
-  if (sch == 1) return launch_fused(c, a, b);
-  if (ensure_density(c)) return 1;
-  return launch_collide(c, a, b);
+  int rc;
+  if (sch == 3) rc = launch_handover(c, a, b);
+  else if (sch == 1) rc = launch_fused(c, a, b);
+  else rc = ensure_density(c) || launch_collide(c, a, b);
+  if (rc) c->step_open = false;                  // as in bflbm_step_boundary: S[cur] is intact, the step may be retried
+  return rc;
 }
 
 int bflbm_step_finish(bflbm_ctx* c) {
@@ -941,10 +982,10 @@ int bflbm_timer_stop(bflbm_ctx* c, float* ms) {
 
 int bflbm_rng_site_normals(uint64_t seed, uint64_t site, uint32_t noise_index, double* out36) {
   if (!out36) return fail("null argument");
-  static const float tab[BFLBM_NORMAL_TABLE_FLOATS] = BFLBM_NORMAL_TABLE_VALUES;
+  static const double tab[BFLBM_NORMAL_TABLE_N] = BFLBM_NORMAL_TABLE_VALUES;
   bflbm_rng_state st;
   bflbm_rng_seed((uint32_t)seed, (uint32_t)(seed >> 32), site, noise_index, st);
-  for (int k = 0; k < 36; ++k) out36[k] = (k < 33) ? (double)bflbm_normal_from_bits(bflbm_rng_next(st), tab) : 0.;
+  for (int k = 0; k < 36; ++k) out36[k] = (k < 33) ? bflbm_normal_from_bits(bflbm_rng_next(st), tab) : 0.;
   return 0;
 }
 
@@ -990,6 +1031,9 @@ struct bflbm_ring {
   std::vector<hipEvent_t> unpacked;     // per slab: both halo faces stored (recorded on the comm stream)
   std::vector<std::array<bool, 2>> peer_ok;   // per slab: kernels on its device may read the lower / upper neighbour's memory
   size_t bytes = 0;
+  bool overlap = true;                  // false: the faces move after the interior sweep (measures what the overlap buys)
+  int transport = 0;                    // 0: gather kernel reading the neighbour in place where reachable; 1: copy engine, one copy per plane
+  int last_kernel_faces = 0, last_copy_faces = 0;   // what the last exchange used
 };
 
 // Halo exchange of the ring without staging: every (component, plane) entry of the halo table is one
@@ -1009,6 +1053,7 @@ static int ring_mark(bflbm_ring* r) {
 static int ring_copy(bflbm_ring* r, int kind) {
   const int n = (int)r->ctx.size();
   if (n == 1) return 0;
+  r->last_kernel_faces = r->last_copy_faces = 0;
   for (int k = 0; k < n; ++k) {
     bflbm_ctx* c = r->ctx[k];
     const int lower = (k + n - 1) % n, upper = (k + 1) % n;
@@ -1029,13 +1074,15 @@ static int ring_copy(bflbm_ring* r, int kind) {
       // BFLBM_RING_COPY_FALLBACK=1 forces the per-plane copies (what a pair of GPUs without peer mapping gets), so that
       // both branches are exercised on a one-GPU box (tests/test_gpu_slabs.py)
       static const bool force_copies = [] { const char* e = getenv("BFLBM_RING_COPY_FALLBACK"); return e && atoi(e) != 0; }();
-      const bool reachable = !force_copies && ((src->dom.device == c->dom.device) || r->peer_ok[k][side]);
+      const bool reachable = !force_copies && r->transport == 0 && ((src->dom.device == c->dom.device) || r->peer_ok[k][side]);
       if (reachable && (c->G.plane % 2 == 0) && (c->G.vol % 2 == 0) && (src->G.vol % 2 == 0)) {
+        ++r->last_kernel_faces;
         // one gather kernel per face reads the neighbour's planes in place (peer memory over xGMI between GPUs)
         dim3 g((unsigned)((c->G.plane / 2 + 255) / 256), (unsigned)(2 * Q));
         hipLaunchKernelGGL(k_halo_pull, g, dim3(256), 0, r->comm[k], dst_base, src_base, c->G.plane, c->G.vol, src->G.vol, Tu, Tp);
         HIP_TRY(hipGetLastError());
       } else {
+        ++r->last_copy_faces;
         for (int e = 0; e < 2 * Q; ++e) {
           double* d = dst_base + (size_t)Tu.comp[e] * c->G.vol + (size_t)Tu.plane[e] * c->G.plane;
           const double* sp = src_base + (size_t)Tp.comp[e] * src->G.vol + (size_t)Tp.plane[e] * src->G.plane;
@@ -1163,8 +1210,35 @@ int bflbm_ring_commit_upload(bflbm_ring* r, int reset) {
   if (!r) return fail("null ring");
   if (ring_exchange(r, BFLBM_HALO_UPLOAD) || ring_join(r)) return 1;
   for (bflbm_ctx* c : r->ctx) if (bflbm_commit_upload(c, reset)) return 1;
+  {                                                         // every slab resolves `auto` on the whole lattice's total density
+    double m = 0.;
+    for (bflbm_ctx* c : r->ctx) m = std::max(m, c->total_max);
+    for (bflbm_ctx* c : r->ctx) c->total_max = m;
+  }
   if (ring_exchange(r, BFLBM_HALO_STATE) || ring_join(r)) return 1;
   return bflbm_ring_sync(r);
+}
+
+// 1 (default): the faces move behind the interior sweep; 0: after it (what bench.py reports as halo_overlap)
+int bflbm_ring_set_overlap(bflbm_ring* r, int on) {
+  if (!r) return fail("null ring");
+  r->overlap = on != 0;
+  return 0;
+}
+// 0 (default): one gather kernel per face reads the neighbour's planes in place (peer memory over xGMI) where the
+// neighbour is reachable, per-plane copies otherwise; 1: always the copy engine (hipMemcpyPeerAsync, 38 copies per face:
+// no compute units, so nothing competes with the one-workgroup-per-CU interior sweep)
+int bflbm_ring_set_transport(bflbm_ring* r, int transport) {
+  if (!r) return fail("null ring");
+  if (transport < 0 || transport > 1) return fail("unknown ring transport %d", transport);
+  r->transport = transport;
+  return 0;
+}
+// faces the last exchange moved with the gather kernel / with the copy engine (2 per slab in total)
+int bflbm_ring_last_transport(const bflbm_ring* r, int* kernel_faces, int* copy_faces) {
+  if (!r || !kernel_faces || !copy_faces) return fail("null argument");
+  *kernel_faces = r->last_kernel_faces; *copy_faces = r->last_copy_faces;
+  return 0;
 }
 
 int bflbm_ring_set_step_count(bflbm_ring* r, long long n) {
@@ -1208,8 +1282,9 @@ int bflbm_ring_step(bflbm_ring* r, int nsteps) {
   for (int s = 0; s < nsteps; ++s) {
     if (ring_prepare_ref(r)) return 1;
     for (bflbm_ctx* c : r->ctx) if (bflbm_step_boundary(c)) return 1;
-    if (ring_mark(r)) return 1;                             // boundary planes final: the neighbours may copy them
+    if (r->overlap && ring_mark(r)) return 1;               // boundary planes final: the neighbours may copy them
     for (bflbm_ctx* c : r->ctx) if (bflbm_step_interior(c)) return 1;   // main streams sweep the interior ...
+    if (!r->overlap && ring_mark(r)) return 1;              // (measurement mode: the faces wait for the whole sweep)
     if (ring_copy(r, BFLBM_HALO_NEXT)) return 1;            // ... while the comm streams move the faces (enqueued after the
                                                             // interior launches so that the 76 copy calls per slab delay nothing)
     if (ring_join(r)) return 1;

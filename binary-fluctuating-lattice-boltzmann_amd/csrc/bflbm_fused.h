@@ -77,7 +77,7 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   static_assert(NW % 2 == 0 && (2 * (TX + 2) + 2 * TY) <= 64 * (NW / 2), "ring tasks of one fluid must fit one per lane of half the waves");
   __shared__ double rp[4][2][LSZ];               // ring of 4 planes x {rho,phi} x (TY+2)x(TX+2)
   __shared__ double gl[Q][TX * TY];              // g populations of the previous plane
-  __shared__ float ntab[MODE == 1 ? BFLBM_NORMAL_TABLE_FLOATS : 4];
+  __shared__ double ntab[MODE == 1 ? BFLBM_NORMAL_TABLE_N : 4];
   __shared__ double n3l[3][MODE == 1 ? TX * TY : 1];   // MODE 1: momentum-mode noise of the site being collided (thread-private column)
   if (MODE == 1) d_load_normal_table(ntab, true);
 
@@ -359,8 +359,8 @@ static inline int fused_plan(const Geo& G, int pa, int pb, int mode, int pair_le
   return TX;
 }
 
-// returns non-zero on launch failure
-static inline int fused_launch(const double* S, double* D, const double* injf, const double* injg,
+// returns the launch's error code
+static inline hipError_t fused_launch(const double* S, double* D, const double* injf, const double* injg,
                                const Geo& G, const DevParams& P, int pa, int pb,
                                uint32_t noise_index, int mode, hipStream_t stream, int pair_len = 0) {
   FusedGrid F;
@@ -374,7 +374,7 @@ static inline int fused_launch(const double* S, double* D, const double* injf, c
   else if (TX == 16)  hipLaunchKernelGGL((k_fused<16, (TX0 * TY0) / 16, 0>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
   else if (TX == 8)   hipLaunchKernelGGL((k_fused<8, (TX0 * TY0) / 8, 0>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
   else                hipLaunchKernelGGL((k_fused<TX0, TY0, 0>), grid, block, 0, stream, S, D, injf, injg, G, P, F, noise_index);
-  return hipGetLastError() != hipSuccess;
+  return hipGetLastError();
 }
 
 #endif  // BFLBM_FUSED_H_

@@ -142,7 +142,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   __shared__ double colacc[2][2][2][TY][6];            // [stage][fluid][side][row][kind] z pipeline of the column lanes
   __shared__ double colfin[2][2][2][TY][6];            // [buf][fluid][side][row][kind] finished column sums
 
-  __shared__ float ntab[MODE == 1 ? BFLBM_NORMAL_TABLE_FLOATS : 4];
+  __shared__ double ntab[MODE == 1 ? BFLBM_NORMAL_TABLE_N : 4];
 
   int col, chunk;
   if (!fused_map(F, (int)blockIdx.x, col, chunk)) return;   // whole workgroup leaves together
@@ -633,8 +633,8 @@ static inline void handover_plan(const Geo& G, int pa, int pb, int pair_len, Fus
 }
 
 // fin/fout: frame buffers of the state read / written.  sig_in: what wrote fin (step == steps-1 required);
-// sig_out receives this launch.  returns non-zero on launch failure
-static inline int handover_launch(const double* S, double* D, const double* fin, double* fout, const Geo& G, const DevParams& P,
+// sig_out receives this launch.  returns the launch's error code
+static inline hipError_t handover_launch(const double* S, double* D, const double* fin, double* fout, const Geo& G, const DevParams& P,
                                   int pa, int pb, long long steps, const HoSig& sig_in, HoSig& sig_out, hipStream_t stream, int pair_len = 0, int mode = 0) {
   constexpr int TX = 64, TY = BFLBM_HO_TY;
   FusedGrid F;
@@ -651,7 +651,7 @@ static inline int handover_launch(const double* S, double* D, const double* fin,
                    else     hipLaunchKernelGGL((k_fused_ho<TY, 1, false>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx); }
   else           { if (rag) hipLaunchKernelGGL((k_fused_ho<TY, 0, true>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
                    else     hipLaunchKernelGGL((k_fused_ho<TY, 0, false>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx); }
-  return hipGetLastError() != hipSuccess;
+  return hipGetLastError();
 }
 
 #endif  // BFLBM_HANDOVER_H_

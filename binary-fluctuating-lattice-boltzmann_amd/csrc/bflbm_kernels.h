@@ -198,6 +198,19 @@ __global__ void __launch_bounds__(256) k_density(const double* __restrict__ S, d
   st_sb(phi + I.pl[1], I.o[1][1], d_density(gs));
 }
 
+// rho,phi of an UPLOADED state: N holds the reference's streamed populations f_i(x) at the site's own slot (bflbm_upload_fg),
+// so the sums need no neighbour (LBM_binary.H:320-330 on the arrays LBM_init copies in, :643-646)
+__global__ void __launch_bounds__(256) k_density_streamed(const double* __restrict__ N, double* __restrict__ rho,
+                                                          double* __restrict__ phi, Geo G, int p0) {
+  BFLBM_SITE_FROM_BLOCK();
+  const long long o = (long long)p*G.plane + s_;
+  double fs[Q], gs[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) { fs[i] = N[(long long)i*G.vol + o]; gs[i] = N[(long long)(i+Q)*G.vol + o]; }
+  rho[o] = d_density(fs);
+  phi[o] = d_density(gs);
+}
+
 // ---- pass B: pull, project (hydrovars), draw noise, collide, store post-collision state
 #ifndef BFLBM_COLLIDE_WAVES
 #define BFLBM_COLLIDE_WAVES 2
@@ -207,7 +220,7 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
                                                  const double* __restrict__ rho, const double* __restrict__ phi,
                                                  const double* __restrict__ injf, const double* __restrict__ injg,
                                                  Geo G, DevParams P, int p0, uint32_t noise_index, RefState Rf) {
-  __shared__ float ntab[(NOISE && !INJECT) ? BFLBM_NORMAL_TABLE_FLOATS : 4];
+  __shared__ double ntab[(NOISE && !INJECT) ? BFLBM_NORMAL_TABLE_N : 4];
   if (NOISE && !INJECT) d_load_normal_table(ntab, true);
   BFLBM_SITE_FROM_BLOCK_XCD();
   SiteOff I; site_offsets(G, x, y, p, I);
@@ -350,7 +363,7 @@ __global__ void __launch_bounds__(256) k_observe(const double* __restrict__ S, c
                                                  const double* __restrict__ injg, double* __restrict__ out,
                                                  Geo G, DevParams P, int p0, uint32_t noise_index, int ncomp, int inject,
                                                  RefState Rf) {
-  __shared__ float ntab[WHAT != 0 ? BFLBM_NORMAL_TABLE_FLOATS : 4];
+  __shared__ double ntab[WHAT != 0 ? BFLBM_NORMAL_TABLE_N : 4];
   if (WHAT != 0) d_load_normal_table(ntab, P.noise_on && !inject);
   BFLBM_SITE_FROM_BLOCK();
   SiteIdx I; site_index(G, x, y, p, I);
@@ -463,6 +476,29 @@ __global__ void __launch_bounds__(256) k_reduce(const double* __restrict__ rho, 
     const long long b = (long long)blockIdx.y*gridDim.x + blockIdx.x;
     for (int k = 0; k < 5; ++k) partial[b*5 + k] = sh[k][0];
   }
+}
+
+// largest |rho + phi| per block over the slab's own planes (what `auto` keys its stability bound on after an upload,
+// bflbm_commit_upload); NaN propagates to the result so that a broken upload is not mistaken for a small one
+__global__ void __launch_bounds__(256) k_total_absmax(const double* __restrict__ rho, const double* __restrict__ phi,
+                                                      double* __restrict__ partial, Geo G, int p0) {
+  __shared__ double sh[256];
+  const long long s_ = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+  const int p = p0 + (int)blockIdx.y;
+  double v = 0.;
+  const int y = (int)(s_ / G.pitch);
+  const int x = (int)(s_ - (long long)y*G.pitch);
+  if (s_ < G.plane && x < G.nx) {
+    const long long o = (long long)p*G.plane + s_;
+    v = fabs(rho[o] + phi[o]);
+  }
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { const double a = sh[threadIdx.x], b = sh[threadIdx.x + w]; sh[threadIdx.x] = (a != a || b != b) ? (a + b) : (a > b ? a : b); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(long long)blockIdx.y*gridDim.x + blockIdx.x] = sh[0];
 }
 
 #endif  // BFLBM_KERNELS_H_

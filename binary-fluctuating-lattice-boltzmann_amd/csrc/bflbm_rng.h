@@ -3,18 +3,18 @@
 // The reference draws amrex::RandomNormal(0,1,engine) (LBM_binary.H:117,125,126),
 // an un-vendored generator whose stream depends on the box decomposition and
 // cannot be reproduced offline.  This project defines its own
-// stream instead (round 2: 2650 -> ~1100 VALU instructions per site):
+// stream instead (round 1: ~2650 VALU instructions per site, rounds 2-3: ~1170, round 4: ~520):
 //   bits     one Philox4x32-10 block (KAT-checked) keyed by `seed` with counter
-//            (site_lo, site_hi, noise_index, 0) seeds xoshiro128++, which supplies the site's
+//            (site_lo, site_hi, noise_index, 0) seeds xoshiro128+, which supplies the site's
 //            33 words (draw order: the 3 momentum modes, modes 4..18 of f, modes 4..18 of g);
 //            site = x + nx*(y + ny*z) is the GLOBAL lattice index, so the noise field is
 //            independent of the slab decomposition and of the GPU count;
-//   normals  table-driven inverse CDF: bit 31 is the sign, the other 31 bits are the tail
-//            probability t = P(|N| > x) as a binary fraction; its octave (leading zeros) and the
-//            next two bits select one of 128 cubics, the next 24 bits are the argument
-//            (tools/make_normal_table.py: max error 2.1e-6, variance 1 + 7e-8, <x^4> 3 - 1.3e-7;
-//            tails to 6.3 sigma).  Three binary32 FMAs -- exactly rounded on the host (fmaf) and on
-//            gfx950 (v_fma_f32) -- and integer operations only, so both give identical bits.
+//   normals  quantile table: s = sum of the four bytes of the word (0..1020, one v_dot4_u32_u8), x = T[s]
+//            (one 8-byte LDS read).  s has the exactly known bell-shaped distribution of a sum of four
+//            uniform bytes; T carries its cumulative cells to the normal quantiles between the same
+//            probabilities (conditional means, unit variance: tools/make_normal_table.py -- 1021 levels,
+//            0.0065 sigma apart in the centre, <x^4> = 3 - 7e-6, outermost level 6.38 sigma).  No floating-
+//            point arithmetic is involved, so host and device agree by construction.
 #ifndef BFLBM_RNG_H_
 #define BFLBM_RNG_H_
 
@@ -34,9 +34,12 @@ BFLBM_HD uint32_t bflbm_mulhi32(uint32_t a, uint32_t b) {
 #endif
 }
 
+#ifndef BFLBM_PHILOX_ROUNDS
+#define BFLBM_PHILOX_ROUNDS 10     // anything else is a timing experiment (tools/), never the product
+#endif
 BFLBM_HD void bflbm_philox4x32_10(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < BFLBM_PHILOX_ROUNDS; ++r) {
 #if defined(BFLBM_PHILOX_MUL64)
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
@@ -51,34 +54,14 @@ BFLBM_HD void bflbm_philox4x32_10(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint
   }
 }
 
-BFLBM_HD float bflbm_u2f(uint32_t i) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __uint_as_float(i);
-#else
-  union { uint32_t i; float f; } v; v.i = i; return v.f;
-#endif
-}
-BFLBM_HD uint32_t bflbm_f2u(float f) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __float_as_uint(f);
-#else
-  union { uint32_t i; float f; } v; v.f = f; return v.i;
-#endif
-}
-BFLBM_HD float bflbm_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }   // one rounding on both sides
-BFLBM_HD uint32_t bflbm_clz32(uint32_t v) {             // 32 for v == 0
-#if defined(__HIP_DEVICE_COMPILE__)
-  return (uint32_t)__clz((int)v);
-#else
-  return v ? (uint32_t)__builtin_clz(v) : 32u;
-#endif
-}
 BFLBM_HD uint32_t bflbm_rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
 
-// xoshiro128++ (Blackman & Vigna): the site's word stream
+// xoshiro128+ (Blackman & Vigna): the site's word stream.  The plain sum is the cheapest of the family's output
+// functions (8 integer instructions per word against 10 for ++); its known weakness, low linear complexity of the
+// lowest bits, is immaterial for a word that is consumed as the sum of its bytes.
 struct bflbm_rng_state { uint32_t s0, s1, s2, s3; };
 BFLBM_HD uint32_t bflbm_rng_next(bflbm_rng_state& s) {
-  const uint32_t result = bflbm_rotl32(s.s0 + s.s3, 7) + s.s0;
+  const uint32_t result = s.s0 + s.s3;
   const uint32_t t = s.s1 << 9;
   s.s2 ^= s.s0; s.s3 ^= s.s1; s.s1 ^= s.s2; s.s0 ^= s.s3;
   s.s2 ^= t;
@@ -91,24 +74,19 @@ BFLBM_HD void bflbm_rng_seed(uint32_t seed_lo, uint32_t seed_hi, uint64_t site, 
   s.s0 = c0; s.s1 = c1; s.s2 = c2; s.s3 = c3 | 1u;     // never the all-zero state
 }
 
-#define BFLBM_NORMAL_TABLE_FLOATS 512
-// standard normal from one 32-bit word; tab = the 128 cubics of bflbm_normal_table.h (LDS on the device)
-template <typename TabPtr>
-BFLBM_HD float bflbm_normal_from_bits(uint32_t u, TabPtr tab) {
-  const uint32_t sign = u & 0x80000000u, v = u & 0x7FFFFFFFu;
-  const uint32_t lz = bflbm_clz32(v);                   // 1..32: octave + 1
+#define BFLBM_NORMAL_TABLE_N 1024      // doubles: levels 0..1020 and three entries of padding (8 KB)
+// byte offset of the word's level in the table: 8 * (b0 + b1 + b2 + b3)
+BFLBM_HD uint32_t bflbm_level_offset(uint32_t u) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const uint32_t top = v << (lz & 31u);                 // v == 0: lz = 32 shifts by 0 and leaves 0 (what the hardware does anyway)
+  return __builtin_amdgcn_udot4(u, 0x08080808u, 0u, false);
 #else
-  const uint32_t top = (lz >= 32u) ? 0u : (v << lz);    // leading one at bit 31
+  return 8u * ((u & 255u) + ((u >> 8) & 255u) + ((u >> 16) & 255u) + (u >> 24));
 #endif
-  const uint32_t r = top << 1;                          // the bits after it, left-aligned
-  const uint32_t oct = (lz - 1u < 31u) ? lz - 1u : 31u; // min(lz - 1, 31)
-  const uint32_t cell = oct * 4u + (r >> 30);
-  const float W = (float)((r >> 6) & 0xFFFFFFu);        // 24 bits: exact
-  const float c0 = tab[cell * 4u + 0u], c1 = tab[cell * 4u + 1u], c2 = tab[cell * 4u + 2u], c3 = tab[cell * 4u + 3u];
-  const float x = bflbm_fmaf(bflbm_fmaf(bflbm_fmaf(c3, W, c2), W, c1), W, c0);
-  return bflbm_u2f(bflbm_f2u(x) ^ sign);
+}
+// standard normal from one 32-bit word; tab = the table of bflbm_normal_table.h (LDS on the device)
+template <typename TabPtr>
+BFLBM_HD double bflbm_normal_from_bits(uint32_t u, TabPtr tab) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(&tab[0]) + bflbm_level_offset(u));
 }
 
 #endif  // BFLBM_RNG_H_

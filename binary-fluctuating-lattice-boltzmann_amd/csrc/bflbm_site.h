@@ -262,7 +262,8 @@ __device__ __forceinline__ void d_gradient(const DevParams& P, const double (&nb
 // (2/3, 4/3, 4/9, 1/9, 2/9, 2; LBM_d3q19.H:56-76): sqrt(c*b) is uniform (host, DevParams.samp) and the site
 // contributes sqrt|rho|, sqrt|phi| -- 3 square roots per site instead of the 31 of the reference's loop.  (The
 // generated noise is pinned statistically only; the oracle restates the same factorisation, so GPU and
-// oracle agree bit for bit.)  Normals: the site's word stream, bflbm_rng.h; words 0..2 the momentum modes shared
+// oracle agree bit for bit, and tests/test_oracle_pins.py bounds the factorised amplitude against the reference's
+// literal expression.)  Normals: the site's word stream, bflbm_rng.h; words 0..2 the momentum modes shared
 // by both fluids, 3..17 fluid f, 18..32 fluid g, so each fluid's noise is generated right before its relaxation.
 struct NoiseAmp { double sj, sr, sp; };          // sqrt(amp_j |rho phi/rhot|), sqrt|rho|, sqrt|phi|
 __device__ __forceinline__ int d_noise_group(int a) {   // modes 4..18 -> index of b[a] among the six values
@@ -278,7 +279,7 @@ __device__ __forceinline__ void d_noise_amp(const DevParams& P, double rho, doub
 // noise of mode a >= 4 of one fluid (s = A.sr or A.sp), drawing the next word of the site's stream
 template <typename Tab>
 __device__ __forceinline__ double d_noise_mode(const DevParams& P, double s, int a, Tab tab, bflbm_rng_state& st) {
-  return (P.samp[d_noise_group(a)] * s) * (double)bflbm_normal_from_bits(bflbm_rng_next(st), tab);
+  return (P.samp[d_noise_group(a)] * s) * bflbm_normal_from_bits(bflbm_rng_next(st), tab);
 }
 // seeds the site's stream and draws the momentum-mode noise (modes 1..3 of f; g gets the negative)
 template <typename Tab>
@@ -286,7 +287,7 @@ __device__ __forceinline__ void d_noise_head(const DevParams& P, const NoiseAmp&
                                              bflbm_rng_state& st, double (&fn3)[3]) {
   bflbm_rng_seed(P.seed_lo, P.seed_hi, site, idx, st);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) fn3[k] = A.sj * (double)bflbm_normal_from_bits(bflbm_rng_next(st), tab);
+  for (int k = 0; k < 3; ++k) fn3[k] = A.sj * bflbm_normal_from_bits(bflbm_rng_next(st), tab);
 }
 template <typename Tab>
 __device__ __forceinline__ void d_noise_f(const DevParams& P, const NoiseAmp& A, Tab tab, bflbm_rng_state& st, const double (&fn3)[3], double (&fn)[Q]) {
@@ -312,9 +313,9 @@ __device__ __forceinline__ void d_noise(const DevParams& P, double rho, double p
 }
 
 // the normal table in LDS: every thread of the workgroup calls this before any early exit
-__constant__ float bflbm_normal_table_dev[BFLBM_NORMAL_TABLE_FLOATS] = BFLBM_NORMAL_TABLE_VALUES;
-__device__ __forceinline__ void d_load_normal_table(float* lds, bool wanted) {
-  if (wanted) for (int i = threadIdx.x; i < BFLBM_NORMAL_TABLE_FLOATS; i += blockDim.x) lds[i] = bflbm_normal_table_dev[i];
+__constant__ double bflbm_normal_table_dev[BFLBM_NORMAL_TABLE_N] = BFLBM_NORMAL_TABLE_VALUES;
+__device__ __forceinline__ void d_load_normal_table(double* lds, bool wanted) {
+  if (wanted) for (int i = threadIdx.x; i < BFLBM_NORMAL_TABLE_N; i += blockDim.x) lds[i] = bflbm_normal_table_dev[i];
   __syncthreads();
 }
 
@@ -434,20 +435,19 @@ __device__ __forceinline__ void d_relax(const DevParams& P, double (&m)[Q], doub
   d_relax_with<NOISE>(P, m, rho_k, v_b, u, a, inv_tau_bar, [&](int k) { return noise[k]; }, ycs4);
 }
 // relaxation of one fluid with the generated stream: n3 = its momentum-mode noise (fn3 or -fn3), s = A.sr / A.sp.
-// The fluid's 15 normals are drawn first as binary32 (their 15 table look-ups are in flight together), the
-// doubles are formed where they are added.
+// The fluid's 15 normals are drawn first (their 15 table look-ups are in flight together) and scaled where they are added.
 template <typename Tab>
 __device__ __forceinline__ void d_relax_generated(const DevParams& P, double (&m)[Q], double rho_k, const double (&v_b)[3],
                                                   const double (&u)[3], const double (&a)[3], double inv_tau_bar,
                                                   const double (&n3)[3], double s, Tab tab, bflbm_rng_state& st, double ycs4) {
-  float nrm[Q - 4];
+  double nrm[Q - 4];
 #pragma unroll
   for (int k = 4; k < Q; ++k) nrm[k - 4] = bflbm_normal_from_bits(bflbm_rng_next(st), tab);
   double amp[6];                                 // the six distinct amplitudes of this fluid (same products as d_noise_mode)
 #pragma unroll
   for (int g = 0; g < 6; ++g) amp[g] = P.samp[g] * s;
   d_relax_with<true>(P, m, rho_k, v_b, u, a, inv_tau_bar,
-                     [&](int k) { return k == 0 ? 0. : (k < 4 ? n3[k - 1] : amp[d_noise_group(k)] * (double)nrm[k - 4]); }, ycs4);
+                     [&](int k) { return k == 0 ? 0. : (k < 4 ? n3[k - 1] : amp[d_noise_group(k)] * nrm[k - 4]); }, ycs4);
 }
 
 __device__ __forceinline__ void d_barycentric(double rho, double phi, const SiteHydro& H, double (&v_b)[3], const SiteRecip& R) {

@@ -251,6 +251,17 @@ class BinaryLBM(_DropletMixin):
         """Absolute step of the resident state = noise index of the next step (restart from a kBT > 0 checkpoint)."""
         check(self.lib.bflbm_set_step_count(self._h, int(n)))
 
+    @property
+    def state_total_max(self):
+        """Largest |rho + phi| of the state the last LBM_init(f0, g0) made resident (what `auto` keys its stability bound
+        on); negative after an analytic init, where rho_hi + rho_lo of the parameters is that number."""
+        v = ctypes.c_double()
+        check(self.lib.bflbm_state_total_max(self._h, ctypes.byref(v)))
+        return v.value
+
+    def set_state_total_max(self, v):
+        check(self.lib.bflbm_set_state_total_max(self._h, float(v)))
+
     # -- state and per-step fields -------------------------------------------------------------
     def populations(self, f=None, g=None, fab=None):
         """fold, gold valid cells (post-stream state of the last completed step)."""
@@ -522,6 +533,23 @@ class RingLBM(_DropletMixin):
 
     def set_steps_done(self, n):
         check(self.lib.bflbm_ring_set_step_count(self._h, int(n)))
+
+    TRANSPORTS = {"kernel": 0, "copy": 1}
+
+    def set_transport(self, transport):
+        """How the faces move: "kernel" (default) = one gather kernel per face reading the neighbour's planes in place
+        (peer memory over xGMI); "copy" = the copy engine, 38 hipMemcpyPeerAsync per face, no compute units."""
+        check(self.lib.bflbm_ring_set_transport(self._h, int(self.TRANSPORTS.get(transport, transport))))
+
+    def set_overlap(self, on):
+        """False: the faces move after the interior sweep instead of behind it (measures what the overlap buys)."""
+        check(self.lib.bflbm_ring_set_overlap(self._h, 1 if on else 0))
+
+    def last_transport(self):
+        """(faces moved by the gather kernel, faces moved by the copy engine) in the last exchange."""
+        a, b = ctypes.c_int(), ctypes.c_int()
+        check(self.lib.bflbm_ring_last_transport(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
 
 def rng_site_normals(seed, site, noise_index):

@@ -177,6 +177,12 @@ class SlabLattice(_Protocol):
             self.exchange(_lib.HALO_UPLOAD)
         self.engine.commit_upload(True)
         if self.world > 1:
+            # every rank resolves `auto` on the whole lattice's total density, not on its own slab's (csrc/bflbm.hip
+            # handover_contract_params): one all-reduce of a scalar
+            if hasattr(self.engine, "set_state_total_max"):
+                m = self.torch.tensor([self.engine.state_total_max], dtype=self.torch.float64, device=self.device)
+                self.dist.all_reduce(m, op=self.dist.ReduceOp.MAX, group=self.group)
+                self.engine.set_state_total_max(float(m.item()))
             self.exchange(_lib.HALO_STATE)
 
     def populations(self, *a, **k):
@@ -214,6 +220,15 @@ class SlabLattice(_Protocol):
 
     def sync(self):
         self.engine.sync()
+
+    @property
+    def steps_done(self):
+        return self.engine.steps_done
+
+    def set_steps_done(self, n):
+        """Absolute step of the resident state = noise index of the next step: a restart from a kBT > 0 checkpoint
+        continues the stream instead of replaying the first segment's normals (main_run_job.cpp:80 step_continue)."""
+        self.engine.set_steps_done(n)
 
     def close(self):
         self.engine.close()

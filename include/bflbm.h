@@ -100,7 +100,9 @@ int bflbm_set_stream(bflbm_ctx* c, void* hip_stream, int external);
  *      handled) and no injected noise, otherwise it resolves to the bit-exact schedule (1 at zero noise, 0 with noise).
  *      Fails if its frames (5.6 % of the state) cannot be allocated.
  *   2  auto (default): 3 where it applies AND is the faster kernel (marches of >= 16 planes; at zero noise a last tile
- *      column with >= 77 % of its lanes busy) AND alpha0 (|rho_hi| + |rho_lo|) <= 6 AND the frames fit in device memory;
+ *      column with >= 77 % of its lanes busy) AND alpha0 x (total density) <= 6, the total density rho + phi being
+ *      |rho_hi| + |rho_lo| after an analytic init and the largest |rho + phi| of the uploaded state after LBM_init
+ *      (bflbm_state_total_max), AND the frames fit in device memory;
  *      else a bit-exact schedule: 0 with noise, and at zero noise 1, or 0 on lattices too small to give the one-pass kernel
  *      a workgroup per CU.  BFLBM_AUTO_EXACT=1 in the environment keeps auto bit-exact, with and without noise.
  * Schedules 0 and 1 give the CPU reference's doubles (same operation order).  Schedule 3 adds the 19 populations of
@@ -125,6 +127,12 @@ int bflbm_init_droplet(bflbm_ctx* c, double r);
  * Call once per box of a multi-box MultiFab, then bflbm_commit_upload(). */
 int bflbm_upload_fg(bflbm_ctx* c, const double* f, const double* g, const bflbm_fab* box);
 int bflbm_commit_upload(bflbm_ctx* c, int reset_step_counter);
+/* The total density `auto` keys its stability bound on (bflbm_set_schedule): the largest |rho + phi| of the state the last
+ * bflbm_commit_upload made resident (LBM_init, LBM_binary.H:632-661), or a negative number after an analytic init (then
+ * rho_hi + rho_lo of the parameters is that number at every site).  A driver that owns several slabs hands each slab the
+ * maximum over all of them (bflbm_ring_commit_upload does). */
+int bflbm_state_total_max(const bflbm_ctx* c, double* total_max);
+int bflbm_set_state_total_max(bflbm_ctx* c, double total_max);
 
 /* fold/gold valid cells after LBM_timestep (state t): write the slab's cells
  * that lie inside `box` into f,g (ghost cells of the destination are not touched). */
@@ -192,6 +200,13 @@ int bflbm_ring_init_droplet(bflbm_ring* r, double radius);
 /* after bflbm_upload_fg on every slab: exchange the uploaded faces, commit, exchange the state faces */
 int bflbm_ring_commit_upload(bflbm_ring* r, int reset_step_counter);
 int bflbm_ring_set_step_count(bflbm_ring* r, long long steps_done);   /* see bflbm_set_step_count */
+/* How the ring moves its faces (the reference's FillBoundary, LBM_binary.H:553-555).  overlap 1 (default): behind the
+ * interior sweep, 0: after it (a measurement mode).  transport 0 (default): one gather kernel per face reads the
+ * neighbour's planes in place (peer memory over xGMI) where the neighbour is reachable; 1: the copy engine, 38
+ * hipMemcpyPeerAsync per face -- no compute units.  bflbm_ring_last_transport: faces the last exchange moved either way. */
+int bflbm_ring_set_overlap(bflbm_ring* r, int on);
+int bflbm_ring_set_transport(bflbm_ring* r, int transport);
+int bflbm_ring_last_transport(const bflbm_ring* r, int* kernel_faces, int* copy_faces);
 int bflbm_ring_step(bflbm_ring* r, int nsteps);            /* LBM_timestep x nsteps on the whole lattice */
 int bflbm_ring_com_sums(bflbm_ring* r, double sums[4]);    /* update_com sums over all slabs */
 int bflbm_ring_mass(bflbm_ring* r, double* rho_sum, double* phi_sum);

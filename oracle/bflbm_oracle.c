@@ -234,15 +234,14 @@ void orc_populations(const double* mom, double* f) {
 /* Project RNG (replaces amrex::RandomNormal, LBM_binary.H:117,125,126, whose stream is not available
  * offline -- parity unpinned at that boundary).  Per (site, noise index): one Philox4x32-10
  * block (Salmon et al., SC'11) keyed by the seed with counter (site lo, site hi, noise index, 0) seeds
- * xoshiro128++ (Blackman & Vigna), whose first 33 words become the site's 33 normals through a
- * table-driven inverse CDF: bit 31 = sign, the other 31 bits = tail probability P(|N| > x) as a binary
- * fraction; octave (leading zeros) and the next two bits pick one of 128 cubics (normal_table.h, generated
- * by tools/make_normal_table.py), the next 24 bits are its argument; three binary32 FMAs (fmaf: one
- * rounding each), integer operations otherwise, so the HIP kernels reproduce it bit for bit.  The
- * product-side definition lives in csrc/bflbm_rng.h; tests/test_oracle_pins.py and tests/test_gpu_noise.py
- * check that the two agree. */
+ * xoshiro128+ (Blackman & Vigna), whose first 33 words become the site's 33 normals through a quantile
+ * table: s = sum of the word's four bytes (0..1020) has the exactly known distribution of a sum of four
+ * uniform bytes, and T[s] (normal_table.h, generated by tools/make_normal_table.py) is the mean of N(0,1)
+ * between the normal quantiles of that cell's cumulative probabilities, scaled to unit variance.  Integer
+ * operations and one table read, so the HIP kernels reproduce it bit for bit.  The product-side definition
+ * lives in csrc/bflbm_rng.h; tests/test_oracle_pins.py and tests/test_gpu_noise.py check that the two agree. */
 #include "normal_table.h"
-static const float NORMAL_TABLE[512] = ORC_NORMAL_TABLE_VALUES;
+static const double NORMAL_TABLE[1024] = ORC_NORMAL_TABLE_VALUES;
 
 static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                  uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -260,8 +259,8 @@ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
 }
 
 static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
-static inline uint32_t xoshiro128pp(uint32_t s[4]) {
-  const uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
+static inline uint32_t xoshiro128p(uint32_t s[4]) {
+  const uint32_t result = s[0] + s[3];
   const uint32_t t = s[1] << 9;
   s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
   s[2] ^= t;
@@ -270,20 +269,8 @@ static inline uint32_t xoshiro128pp(uint32_t s[4]) {
 }
 
 /* one standard normal from one 32-bit word */
-static inline float normal_from_bits(uint32_t u) {
-  const uint32_t sign = u & 0x80000000u, v = u & 0x7FFFFFFFu;
-  uint32_t oct, r;
-  if (v == 0u) { oct = 31u; r = 0u; }
-  else {
-    const uint32_t lz = (uint32_t)__builtin_clz(v);   /* >= 1: bit 31 is clear */
-    oct = lz - 1u;                                     /* t in [2^-(oct+1), 2^-oct) */
-    r = (v << lz) << 1;                                /* the bits after the leading one, left-aligned */
-  }
-  const float* c = NORMAL_TABLE + 4u*(oct*4u + (r >> 30));
-  const float W = (float)((r >> 6) & 0xFFFFFFu);
-  const float x = fmaf(fmaf(fmaf(c[3], W, c[2]), W, c[1]), W, c[0]);
-  union { float f; uint32_t i; } o; o.f = x; o.i ^= sign;
-  return o.f;
+static inline double normal_from_bits(uint32_t u) {
+  return NORMAL_TABLE[(u & 255u) + ((u >> 8) & 255u) + ((u >> 16) & 255u) + (u >> 24)];
 }
 
 /* The 33 normals of one site for one noise index (out36[33..35] = 0; the array length is the C-ABI's). */
@@ -291,7 +278,7 @@ void orc_site_normals(uint64_t seed, uint64_t site, uint32_t noise_index, double
   uint32_t s[4];
   philox4x32_10((uint32_t)site, (uint32_t)(site >> 32), noise_index, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), s);
   s[3] |= 1u;                                          /* never the all-zero state */
-  for (int k = 0; k < 36; ++k) out36[k] = (k < 33) ? (double)normal_from_bits(xoshiro128pp(s)) : 0.;
+  for (int k = 0; k < 36; ++k) out36[k] = (k < 33) ? normal_from_bits(xoshiro128p(s)) : 0.;
 }
 
 void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {

@@ -8,6 +8,7 @@ against stand-in AMReX types: they are a regression check of the oracle, not a p
 outputs.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -203,13 +204,46 @@ def test_rng_stream_properties(ob):
     assert abs(x.mean()) < 0.005
     assert abs(x.var() - 1.0) < 0.01
     assert abs((x ** 4).mean() - 3.0) < 0.08
-    assert np.abs(x).max() < 6.0
+    assert np.abs(x).max() < 6.39                     # the outermost level of the quantile table
     # Philox4x32-10 known answer (Random123 kat_vectors: counter 0, key 0)
     out = (ctypes.c_uint32 * 4)()
     ob.lib().orc_philox(0, 0, 0, 0, 0, 0, out)
     assert [hex(v) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
     ob.lib().orc_philox(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, out)
     assert [hex(v) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+def test_normal_table_is_the_quantile_map_of_the_byte_sum():
+    """The stream's normals are T[sum of the word's four bytes] (csrc/bflbm_rng.h).  The byte sum has exactly known
+    probabilities (4-fold convolution of 256 ones / 2^32), so the distribution the table defines is checked EXACTLY,
+    not by sampling: mean 0, variance 1 to rounding, fourth and sixth moments of a Gaussian to 1e-5 relative, and every
+    cell edge on the normal quantile of its cumulative probability (the level lies between the quantiles of its cell)."""
+    import re
+    from scipy import special
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tabs = []
+    for rel in ("oracle/normal_table.h", "binary-fluctuating-lattice-boltzmann_amd/csrc/bflbm_normal_table.h"):
+        txt = open(os.path.join(root, rel)).read()
+        vals = [float.fromhex(v) for v in re.findall(r"-?0x[0-9a-f.]+p[+-]\d+", txt)]
+        assert len(vals) == 1024
+        tabs.append(np.array(vals))
+    assert np.array_equal(tabs[0], tabs[1])            # the library's copy and the oracle's copy are the same data
+    T = tabs[0][:1021]
+    assert np.all(tabs[0][1021:] == 0) and np.array_equal(T, -T[::-1]) and np.all(np.diff(T) > 0)
+    c = np.ones(256)
+    for _ in range(3):
+        c = np.convolve(c, np.ones(256))
+    p = c / 2.0 ** 32
+    assert abs(p.sum() - 1) < 1e-15
+    assert abs((p * T).sum()) < 1e-16
+    assert abs((p * T ** 2).sum() - 1) < 1e-14
+    assert abs((p * T ** 4).sum() - 3) < 3e-5
+    assert abs((p * T ** 6).sum() - 15) < 2e-4
+    cum = np.cumsum(p)
+    edges = special.ndtri(cum[:510])                   # upper edges of cells 0..509 (lower half; the table is symmetric)
+    scale = 1.0 / np.sqrt(0.999996110308)              # the factor that restores unit variance (tools/make_normal_table.py)
+    assert np.all(T[:510] < edges * scale + 1e-12) and np.all(T[1:511] > edges * scale - 1e-12)
+    assert abs(T[0] + 6.3834) < 1e-3 and abs((T[511] - T[510]) - 0.006528) < 1e-5
 
 
 def test_ref_state_branch_of_the_oracle(ob):

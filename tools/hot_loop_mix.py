@@ -17,8 +17,7 @@ for mode in modes:
     for i, l in enumerate(body):
         m = re.match(r'\s+s_c?branch\S*\s+(\.LBB\d+_\d+)', l)
         if m and m.group(1) in lab and lab[m.group(1)] < i: loops.append((lab[m.group(1)], i))
-    k = [i for i, l in enumerate(body) if 'vmcnt(62)' in l][0]           # the loop head that waits for loads only
-    lp = min([x for x in loops if x[0] <= k <= x[1]], key=lambda x: x[1] - x[0])
+    lp = max(loops, key=lambda x: x[1] - x[0])                            # the steady-state march loop is by far the longest
     cnt = collections.Counter()
     for l in body[lp[0]:lp[1] + 1]:
         t = l.strip().split(';')[0].split()

@@ -1,6 +1,6 @@
 // Probe: do the primitives of csrc/bflbm_rng.h give the same bits on the host and on gfx950?
-// normals of 2^24 random words (fmaf cubic + integer decode), the xoshiro128++/Philox stream of 2^16 sites, and
-// the correctly rounded binary64 sqrt and division the amplitudes rely on.
+// normals of 2^24 random words (v_dot4_u32_u8 byte sum on the device, shifts and adds on the host; one table read), the
+// xoshiro128+/Philox stream of 2^24 sites, and the correctly rounded binary64 sqrt and division the amplitudes rely on.
 // build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o build/probe/rng_probe tools/rng_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -10,10 +10,10 @@
 #include "../binary-fluctuating-lattice-boltzmann_amd/csrc/bflbm_rng.h"
 #include "../binary-fluctuating-lattice-boltzmann_amd/csrc/bflbm_normal_table.h"
 
-__constant__ float tab_dev[BFLBM_NORMAL_TABLE_FLOATS] = BFLBM_NORMAL_TABLE_VALUES;
-static const float tab_host[BFLBM_NORMAL_TABLE_FLOATS] = BFLBM_NORMAL_TABLE_VALUES;
+__constant__ double tab_dev[BFLBM_NORMAL_TABLE_N] = BFLBM_NORMAL_TABLE_VALUES;
+static const double tab_host[BFLBM_NORMAL_TABLE_N] = BFLBM_NORMAL_TABLE_VALUES;
 
-struct Out { float nrm; float site[33]; double sq64, dv64; };
+struct Out { double nrm; double site[33]; double sq64, dv64; };
 
 template <typename Tab>
 __host__ __device__ inline void eval(uint32_t a, uint32_t b, Tab tab, Out& o) {
