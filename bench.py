@@ -220,19 +220,19 @@ def supervise(a):
             outf.close()
         return flag[0], line, note, round(time.time() - t0, 1)
 
-    tried, result = [], None
+    tried, result, done = [], None, False              # result: the line (rank 0 only); done: a transport completed (all ranks)
     for k, transport in enumerate(chain):
         ok, line, note, secs = attempt(transport, a.attempt_timeout)
         tried.append({"transport": transport, "ok": bool(ok), "seconds": secs, **({"note": note} if note else {})})
         if rank == 0:
             print(f"[bench] transport {transport}: {'ok' if ok else 'FAILED (' + note + ')'} after {secs} s", file=sys.stderr, flush=True)
         if ok:
-            result = line
+            result, done = line, True
             break
     # Informational: the next transport FAMILY (peer after rccl, rccl after peer) in the same run, when the first attempt left
     # time for it -- the driver's scaling run is the only multi-GPU measurement a round gets.  Never allowed to cost the line.
     second = None
-    if result is not None and a.transport == "auto" and not a.no_second_transport:
+    if done and a.transport == "auto" and not a.no_second_transport:
         fam = tried[-1]["transport"].split("-")[0]
         alt = next((t for t in TRANSPORT_CHAIN if t.split("-")[0] != fam and t not in [x["transport"] for x in tried]), None)
         go = [alt is not None and time.time() - t_begin < 200.0]
@@ -252,10 +252,9 @@ def supervise(a):
         print(json.dumps(result), flush=True)
     dist.barrier()
     dist.destroy_process_group()
-    if result is None and rank == 0:
+    if not done and rank == 0:
         print(f"[bench] no transport completed: {tried}", file=sys.stderr, flush=True)
-    ok_all = [result is not None]
-    raise SystemExit(0 if (rank != 0 or ok_all[0]) else 1)
+    raise SystemExit(0 if done else 1)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -13,8 +13,8 @@ overlaps the interior planes of the same step:
 Every (component, plane) entry of a face is one contiguous plane of the state buffer, so the sends are posted straight
 from the planes the boundary kernels wrote and the receives straight into the halo planes the next step pulls from
 (`halo_plane_tensors`): no pack/unpack kernels, no buffers.  With two ranks both faces go to the same peer in that one
-batch.  An engine without `halo_plane_tensors`, or BFLBM_SLAB_STAGED=1, takes the staged path (pack -> one message per
-face -> unpack) instead.
+batch.  An engine without `halo_plane_tensors`, BFLBM_SLAB_TRANSPORT=staged, or -- until the direct path has been seen to
+work on several GPUs -- the RCCL backend by default, takes the staged path (pack -> one message per face -> unpack).
 
 torch.distributed is plumbing only (process group, P2P); all lattice work is in the HIP library.
 `engine_factory` lets the CPU test-suite drive the same protocol with a stand-in engine.
@@ -101,7 +101,19 @@ class SlabLattice(_Protocol):
         # RCCL orders its work after the current stream by itself; host-driven backends (gloo) read
         # the send buffers from the host side, so the pack kernels must have completed first.
         self._host_sync = dist.get_backend(group) != "nccl"
-        self.direct = hasattr(engine, "halo_plane_tensors") and os.environ.get("BFLBM_SLAB_STAGED", "0") != "1"
+        # Which exchange: "direct" (38 plane-sized P2P operations per face between the state buffers, no staging kernels)
+        # or "staged" (pack -> one message per face -> unpack).  Over RCCL the default is STAGED until the direct path has
+        # one verified multi-GPU run (152 P2P operations in one group, receives landing in live state planes: ADVICE r3);
+        # the staging kernels move 6 x 38 planes of the 38 x nz the step moves anyway.  Host-driven backends (gloo) take the
+        # direct path.  BFLBM_SLAB_TRANSPORT=direct|staged (or the older BFLBM_SLAB_STAGED=1) decides explicitly.
+        want = os.environ.get("BFLBM_SLAB_TRANSPORT", "").strip().lower()
+        if os.environ.get("BFLBM_SLAB_STAGED", "0") == "1":
+            want = "staged"
+        if want not in ("", "direct", "staged"):
+            raise ValueError(f"BFLBM_SLAB_TRANSPORT={want!r}: expected direct or staged")
+        if want == "":
+            want = "staged" if dist.get_backend(group) == "nccl" else "direct"
+        self.direct = hasattr(engine, "halo_plane_tensors") and want == "direct"
         if self.world > 1 and not self.direct:
             n = engine.halo_bytes(_lib.HALO_STATE) // 8
             mk = lambda: torch.empty(n, dtype=torch.float64, device=self.device)

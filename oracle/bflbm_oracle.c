@@ -332,7 +332,7 @@ static void thermal_noise_impl(const orc_params* p, int nx, int ny, int nz, int 
      * nrm[0..2] -> momentum modes 1..3 (gn = -fn), nrm[3 + (a-4)] -> f mode a, nrm[18 + (a-4)] -> g mode a;
      * a = 4..18.  The reference interleaves f,g draws (:124-127), which is immaterial for an i.i.d. stream.
      * Amplitudes (:117, :125-126): sqrt(c kBT |rho phi/rhot|) and sqrt(c kBT/cs2 b[a] |rho|), the latter
-     * evaluated as sqrt(c kBT/cs2 b[a]) * sqrt(|rho|) -- the same number to an ulp with 3 instead of 31 square
+     * evaluated as sqrt(c kBT/cs2 b[a]) * sqrt(|rho|) -- within 2 ulp of it (tests/test_oracle_pins.py) with 3 instead of 31 square
      * roots per site; project-defined like the stream (the generated noise is pinned statistically only). */
     fn[IDX(nx,ny,nz,0,x,y,z)] = 0.;
     gn[IDX(nx,ny,nz,0,x,y,z)] = 0.;

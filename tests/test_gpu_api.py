@@ -97,3 +97,76 @@ def test_device_bytes_and_timer(pkg):
     assert lbm.timer_stop() > 0.0
     assert lbm.debug_time_kernel(0, 3) > 0.0
     lbm.close()
+
+
+def test_auto_keys_its_stability_bound_on_the_uploaded_state(pkg, ob):
+    """`auto` takes the hand-over kernel only while alpha0 x (total density) <= 6 (csrc/bflbm.hip).  After an analytic init the
+    total density is rho_hi + rho_lo of the parameters; after LBM_init(f0, g0) -- the restart path, LBM_binary.H:632-661 --
+    it is whatever the upload made resident: a checkpoint of a rho_hi = 3 run loaded under HEADER DEFAULTS (alpha0 = 4,
+    rho_hi = 1: 4 <= 6) has interaction strength 12 and must run an exact schedule."""
+    shape = (128, 16, 32)
+    src = ob.OracleLattice(*shape, params=ob.default_params(rho_hi=3.0, alpha0=1.5))
+    src.init_droplet(0.25)
+    lbm = pkg.BinaryLBM(*shape)                                        # header defaults, schedule auto
+    lbm.LBM_init_droplet(0.25)
+    assert lbm.resolved_schedule() == "handover" and lbm.state_total_max < 0
+    lbm.LBM_init(src.f, src.g)
+    assert abs(lbm.state_total_max - 3.0) < 1e-12
+    assert lbm.resolved_schedule() == "fused"
+    lbm.LBM_timestep(3)
+    ref = ob.OracleLattice(*shape)
+    ref.init_from(src.f, src.g)
+    for _ in range(3):
+        ref.timestep()
+    f, g = lbm.populations()
+    assert np.array_equal(f, ref.f) and np.array_equal(g, ref.g)      # exact schedule: the oracle's doubles
+    # the same populations scaled to a total density of 1: inside the bound again
+    lbm.LBM_init(src.f / 3.0, src.g / 3.0)
+    assert abs(lbm.state_total_max - 1.0) < 1e-12 and lbm.resolved_schedule() == "handover"
+    # an analytic init forgets the uploaded state
+    lbm.LBM_init(src.f, src.g)
+    lbm.LBM_init_stripe(0.5)
+    assert lbm.state_total_max < 0 and lbm.resolved_schedule() == "handover"
+    lbm.close()
+    # a ring resolves every slab on the whole lattice's maximum, not on the slab's own: slab 0 holds a total density of 1
+    ring = pkg.RingLBM(128, 16, 64, nslabs=4, devices=(0,))
+    big = ob.OracleLattice(128, 16, 64, params=ob.default_params(rho_hi=3.0, alpha0=1.5))
+    big.init_droplet(0.1)
+    big.f[:, :16] /= 3.0; big.g[:, :16] /= 3.0
+    ring.LBM_init(big.f, big.g)
+    assert all(abs(s.state_total_max - 3.0) < 1e-12 for s in ring.slabs)
+    assert all(s.resolved_schedule() == "fused" for s in ring.slabs)
+    ring.close()
+
+
+def test_failed_frame_allocation_leaves_the_step_closed():
+    """An explicit schedule 3 whose frames cannot be allocated fails BEFORE the step is opened: the resident state
+    is intact, so the caller may switch to an exact schedule and go on, and read observables.  The allocation limit is a
+    debug environment variable read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package()
+for nranks in (1, 2):
+    kw = {} if nranks == 1 else dict(z0=0, z1=16, rank=0, nranks=2)
+    l = pkg.BinaryLBM(128, 8, 32 if nranks == 2 else 16, schedule="handover", **kw)
+    l.LBM_init_stripe(0.5)
+    try:
+        l.step_boundary(); l.step_interior()
+        raise SystemExit("the step did not fail")
+    except pkg.BflbmError as e:
+        assert "frames" in str(e), str(e)
+    h0 = l.LBM_hydrovars_density()                 # not 'inside an open step'
+    l.set_schedule("fused")
+    l.step_boundary(); l.step_interior(); l.step_finish()
+    assert l.steps_done == 1
+    l.close()
+print("ok")
+""" % root
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BFLBM_DEBUG_FRAMES_LIMIT="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]

@@ -4,7 +4,8 @@
               populations and hydrovars for the two exact schedules, and the north-star tolerances (SURVEY 8d:
               rho, phi, rho+phi relative 1e-12; velocities absolute 1e-12 cs) stated explicitly.
   configs[2]  256^3 with thermal noise (NoiseCovariance.ipynb parameters): per-mode variances at the real size.
-  configs[3]  512^3 droplet r = 0.2 in 4 z-slabs of 512x512x128 (native ring on one GPU) == the single context.
+  configs[3]  512^3 droplet r = 0.2 in 4 z-slabs of 512x512x128 (native ring on one GPU) == the single context for the exact
+              schedules, and within the strict tolerances of it under the default schedule (auto -> hand-over).
   configs[4]  a pair of 1024x1024x64 slabs == the single 1024x1024x128 context.
 plus the tolerance contract of the density hand-over schedule (csrc/bflbm_handover.h).
 """
@@ -92,6 +93,25 @@ def test_config3_512_cubed_droplet_in_four_slabs(pkg, schedule):
     r.close()
     for comp in range(9):
         assert np.array_equal(ha[comp], hr[comp]), comp
+
+
+def test_config3_512_cubed_droplet_in_four_slabs_default_schedule(pkg):
+    """configs[3] AS SHIPPED: `auto` resolves to the hand-over kernel in every slab's interior sweep (frames) with pulled
+    rings in the boundary plane pairs -- what bench.py --gpus 4 and every user get.  4 slabs of 512x512x128 against the
+    exact single-context run, 12 steps: first step bit-equal, then the strict SURVEY 8d tolerances at every site."""
+    n = 512
+    a = pkg.BinaryLBM(n, n, n, schedule="fused")
+    a.LBM_init_droplet(0.2)
+    r = pkg.RingLBM(n, n, n, nslabs=4, devices=(0,))                       # schedule: auto (the default)
+    r.LBM_init_droplet(0.2)
+    assert all(s.resolved_schedule() == "handover" for s in r.slabs)
+    a.LBM_timestep(1); r.LBM_timestep(1)
+    assert np.array_equal(a.LBM_hydrovars_density(), r.LBM_hydrovars_density())
+    a.LBM_timestep(11); r.LBM_timestep(11)
+    ha, hr = a.LBM_hydrovars(), r.LBM_hydrovars()
+    a.close(); r.close()
+    assert not np.array_equal(ha, hr)                                      # the frames were in use
+    _tolerances(hr, ha)
 
 
 def test_config4_pair_of_1024x1024x64_slabs(pkg):

@@ -2,13 +2,21 @@
 previous step (csrc/bflbm_handover.h, what `auto` runs on every lattice of full 64 x 4 tiles) -- against the CPU ORACLE
 and against committed oracle trajectories, not against another GPU schedule.  LBM_timestep: LBM_binary.H:545-594.
 
-Contract (include/bflbm.h): the first step after an init pulls its ring and equals the oracle bit for bit; later steps
-differ by a re-ordered sum of 19 numbers at tile-edge sites, which the trajectory carries forward with its own
-conditioning.  The north-star tolerance 1e-12 in the metric of tests/tolerances.py (which says why a bare element-wise
-relative error is not defined for this model's near-vacuum sites)
-are asserted outright for stable runs; `test_named_stress_cases` keeps the four diverging runs of round 2's
-stress.log, where the oracle's own response to a one-ulp perturbation is the yardstick.
+Contract (include/bflbm.h, INTEGRATION.md, README.md -- one sentence, the same in all three): the first step after an
+init or upload equals the oracle bit for bit; later steps differ by a re-ordered sum of 19 numbers at tile-edge sites,
+which the trajectory carries forward with its own conditioning.  What is asserted here, per clause:
+  (1) step 1: bit-equal populations and hydrovars;
+  (2) the STRICT form of SURVEY 8d (rho, phi, rho+phi relative 1e-12 and velocities absolute 1e-12 cs at EVERY site)
+      wherever it holds -- every case that is not in tests/golden/handover_strict_exceptions.json;
+  (3) for the listed cases (near-vacuum sites: a minority density of 1e-9 that changes sign, LBM_binary.H:246-247) the
+      masked metric of tests/tolerances.py at 1e-12 AND the unmasked figures within 10 x the oracle's own response to
+      a one-ulp perturbation of its initial state for the same case; the unmasked maxima are printed beside the masked;
+  (4) populations within 1e-13 of the oracle's.
+`test_named_stress_cases` keeps the four diverging runs of round 2's stress.log.
+BFLBM_STRICT_COLLECT=<file> appends one JSON line per case and checkpoint (tests/golden/make_strict_exceptions.py turns
+the file into the committed list).
 """
+import json
 import os
 import sys
 
@@ -26,7 +34,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def _tolerances(h, href, what=""):
     """tests/tolerances.py: densities to 1e-12 of the field maximum everywhere and element by element where there is
     fluid, velocities to 1e-12 max(cs, |u|) where there is fluid, momentum to 1e-12 of its scale everywhere."""
-    return tolerances.check(h, href, what, 1e-12)
+    e = tolerances.check(h, href, what, 1e-12)
+    if not tolerances.strict(e):
+        print(f"[strict form not met] {what}: unmasked density {e['dens_elem_all']:.2e} velocity/cs {e['vel_abs_all']:.2e}")
+    return e
 
 
 def frames_expected(shape, nslabs=1):
@@ -58,6 +69,46 @@ def _make(pkg, shape, par, nslabs, schedule="handover"):
     return pkg.RingLBM(*shape, nslabs=nslabs, params=p, schedule=schedule)
 
 
+_EXC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "handover_strict_exceptions.json")
+STRICT_EXCEPTIONS = json.load(open(_EXC_PATH))["cases"] if os.path.exists(_EXC_PATH) else {}
+YARDSTICK = 10.0           # listed cases: unmasked error <= this x the oracle's own one-ulp response (and never below 1e-12)
+
+
+def case_id(shape, init, par, nslabs):
+    ptxt = ",".join(f"{k}={par[k]:g}" for k in sorted(par)) or "defaults"
+    return f"{shape[0]}x{shape[1]}x{shape[2]}|{init[0]}:{init[1]:.6g}|{ptxt}|slabs{nslabs}" if len(init) > 1 else \
+           f"{shape[0]}x{shape[1]}x{shape[2]}|{init[0]}|{ptxt}|slabs{nslabs}"
+
+
+def _contract(ob, cid, shape, init, par, checkpoints, errs, what):
+    """Clauses (2) and (3) of the module docstring for one case; errs = {steps: tolerances.errors()}."""
+    collect = os.environ.get("BFLBM_STRICT_COLLECT")
+    if collect:
+        with open(collect, "a") as fh:
+            for steps, e in errs.items():
+                fh.write(json.dumps({"case": cid, "steps": steps, "strict": bool(tolerances.strict(e)), **{k: float(v) for k, v in e.items()}}) + "\n")
+    all_strict = all(tolerances.strict(e) for e in errs.values())
+    for steps, e in errs.items():
+        assert all(e[k] <= 1e-12 for k in tolerances.MASKED), f"{what} step {steps}: {e}"
+    if all_strict:
+        return True
+    worst = {k: max(e[k] for e in errs.values()) for k in ("dens_elem_all", "vel_abs_all")}
+    print(f"[strict form not met] {cid}: unmasked density {worst['dens_elem_all']:.2e} velocity/cs {worst['vel_abs_all']:.2e}; "
+          f"masked {max(max(e[k] for k in tolerances.MASKED) for e in errs.values()):.2e}")
+    if collect:
+        return False
+    assert cid in STRICT_EXCEPTIONS, (f"{what}: the strict SURVEY 8d form (densities rel 1e-12, velocities abs 1e-12 cs at every site) is violated "
+                                      f"and the case is not a listed exception: {worst}")
+    kappa = tolerances.one_ulp_response(ob, shape, init, par, [s for s in checkpoints if s > 1])
+    for steps, e in errs.items():
+        if steps == 1:
+            continue
+        for k in ("dens_elem_all", "vel_abs_all"):
+            bound = max(1e-12, YARDSTICK * kappa[steps][k])
+            assert e[k] <= bound, f"{what} step {steps}: unmasked {k} {e[k]:.2e} > {YARDSTICK:g} x the oracle's one-ulp response {kappa[steps][k]:.2e}"
+    return False
+
+
 def _against_oracle(pkg, ob, shape, init, par, nslabs, checkpoints=(1, 10, 50)):
     ref = ob.OracleLattice(*shape, params=ob.default_params(**par))
     getattr(ref, "init_" + init[0])(*init[1:])
@@ -67,6 +118,7 @@ def _against_oracle(pkg, ob, shape, init, par, nslabs, checkpoints=(1, 10, 50)):
         assert lbm.resolved_schedule() == "handover"
     done = 0
     used_frames = False
+    errs = {}
     for steps in checkpoints:
         for _ in range(steps - done):
             ref.timestep()
@@ -80,9 +132,10 @@ def _against_oracle(pkg, ob, shape, init, par, nslabs, checkpoints=(1, 10, 50)):
             assert np.array_equal(h + 0.0, ref.h + 0.0), what
         else:
             used_frames = used_frames or not (np.array_equal(f, ref.f) and np.array_equal(g, ref.g))
-        _tolerances(h, ref.h, what)
+        errs[steps] = tolerances.errors(h, ref.h)
         assert max(np.abs(f - ref.f).max(), np.abs(g - ref.g).max()) < 1e-13, what
     lbm.close()
+    _contract(ob, case_id(shape, init, par, nslabs), shape, init, par, checkpoints, errs, f"{shape} {init} {par} slabs {nslabs}")
     return used_frames
 
 

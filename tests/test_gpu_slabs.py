@@ -185,32 +185,89 @@ def test_distributed_driver_with_the_handover_schedule(ob):
         assert not exact                                   # the frames were in use
 
 
-def test_bench_two_ranks_on_one_gpu_over_gloo():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), rehearsed with both
-    ranks on the one GPU of this box over gloo: the N > 1 bench path with the hand-over schedule (what auto runs on the
-    512^3 slabs of the real bench) and the staging-free exchange runs, reports one JSON line with n_gpus 2, conserves the
-    mass of the stripe and states the halo size.  A rehearsal of the code path, never a measurement."""
+def _bench(args, env=None, timeout=900):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one supervisor rank per GPU), rehearsed on the
+    one GPU of this box: RCCL refuses several ranks per device, so the rccl transports run over gloo (BFLBM_BENCH_BACKEND)
+    with the ranks sharing the device, and the peer transports put every slab on device 0.  A rehearsal of the code
+    paths, never a measurement."""
     import json
     import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, BFLBM_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--shape", "128,16,12", "--no-cpu-baseline", "--schedule", "handover"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
+    n = args[args.index("--gpus") + 1]
+    e = dict(os.environ, BFLBM_BENCH_BACKEND="gloo", **(env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py")] + list(args) + ["--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, out.stdout
-    r = json.loads(line[0])
+    return json.loads(line[0]), out.stderr
+
+
+@pytest.mark.parametrize("transport,text", [("rccl", "rccl, staged"), ("rccl-direct", "rccl, direct"),
+                                            ("peer-kernel", "a gather kernel reads"), ("peer-copy", "copy engine")])
+def test_bench_two_slabs_on_one_gpu_every_transport(transport, text):
+    """The N > 1 bench path with the hand-over schedule (what auto runs on the 512^3 slabs of the real bench) through each
+    halo transport of the launcher's chain: one JSON line with n_gpus 2, the stripe's mass conserved, the halo size and
+    the transport stated, the exchange-after-sweep leg timed."""
+    r, _ = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--shape", "128,16,12", "--schedule", "handover", "--transport", transport])
     assert r["n_gpus"] == 2 and r["config"]["schedule"] == "handover" and r["scaling"] == "weak"
     assert r["config"]["workload"].startswith("128x16x24")
     assert r["config"]["halo_bytes_per_face"] == 38 * 128 * 16 * 8
+    assert text in r["config"]["halo_transport"], r["config"]["halo_transport"]
+    assert [t["transport"] for t in r["config"]["launcher"]["transports_tried"]] == [transport]
     rho, phi = r["config"]["mass_check"]
     assert abs(rho + phi - 128 * 16 * 24) < 1e-6            # rho + phi = rho_hi + rho_lo = 1 at every site of a stripe
     assert len(r["spread"]["blocks_ms_per_step"]) == 3 and r["value"] > 0
+    ov = r["config"]["halo_overlap"]
+    assert ov and ov["ms_per_step_exchange_after_sweep"] > 0
+
+
+def test_bench_falls_back_to_fresh_workers_with_the_next_transport():
+    """The first transport's last rank dies before the rendezvous (what an RCCL abort looks like from outside): the
+    supervisors end its peers, start fresh workers with the next transport of the chain, and the line says so."""
+    r, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "128,16,12", "--no-second-transport"], env={"BFLBM_BENCH_FAIL": "rccl:exit"})
+    tried = r["config"]["launcher"]["transports_tried"]
+    assert [(t["transport"], t["ok"]) for t in tried] == [("rccl", False), ("peer-kernel", True)]
+    assert "a gather kernel reads" in r["config"]["halo_transport"]
+    assert "4 faces by kernel, 0 by copies" in r["config"]["halo_transport"]
+    assert "FAILED" in err
+    rho, phi = r["config"]["mass_check"]
+    assert abs(rho + phi - 128 * 16 * 24) < 1e-6
+
+
+def test_bench_config3_slab_shape_two_ranks_sharing_the_gpu():
+    """configs[3]'s slab shape as bench.py times it under config.also at N = 4: 512x512x128 per rank, droplet r = 0.2,
+    `auto` (-> the hand-over kernel in the interior sweep, pulled rings in the boundary pairs); two ranks here."""
+    r, _ = _bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--shape", "512,512,128", "--init", "droplet", "--transport", "rccl", "--blocks", "1"])
+    assert r["config"]["schedule"] == "handover" and r["config"]["slab_per_gpu"] == "512x512x128"
+    rho, phi = r["config"]["mass_check"]
+    assert abs(rho + phi - 512 * 512 * 256) < 1e-3
+    assert r["config"]["halo_bytes_per_face"] == 38 * 512 * 512 * 8
+
+
+def test_ring_transports_and_overlap_switch(pkg, ob):
+    """The native ring's faces by the gather kernel (default), by the copy engine (hipMemcpyPeerAsync per plane: the CU-free
+    transport), and with the exchange after the sweep instead of behind it: the same doubles, and the ring says what moved."""
+    n, par = (70, 9, 20), dict(kBT=1e-5, alpha0=2.0, seed=5)
+    ref = ob.OracleLattice(*n, params=ob.default_params(**par))
+    ref.init_droplet(0.3)
+    for _ in range(6):
+        ref.timestep()
+    for transport, overlap, faces in (("kernel", True, (8, 0)), ("copy", True, (0, 8)), ("kernel", False, (8, 0)), ("copy", False, (0, 8))):
+        ring = pkg.RingLBM(*n, nslabs=4, devices=(0,), params=pkg.default_params(**par), schedule="two_pass")
+        ring.set_transport(transport)
+        ring.set_overlap(overlap)
+        ring.LBM_init_droplet(0.3)
+        ring.LBM_timestep(6)
+        assert ring.last_transport() == faces
+        f, g = ring.populations()
+        _same(f, ref.f, f"f {transport} overlap {overlap}")
+        _same(g, ref.g, f"g {transport} overlap {overlap}")
+        ring.close()
 
 
 @pytest.mark.parametrize("schedule", ["two_pass", "fused"])

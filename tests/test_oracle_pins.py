@@ -246,6 +246,52 @@ def test_normal_table_is_the_quantile_map_of_the_byte_sum():
     assert abs(T[0] + 6.3834) < 1e-3 and abs((T[511] - T[510]) - 0.006528) < 1e-5
 
 
+def test_factorised_noise_amplitude_against_the_reference_expression(ob):
+    """thermal_noise (LBM_binary.H:125-126) takes ONE root of the product, sqrt(2 (tb - tb^2/2) kBT/cs2 b[a] |rho|); the
+    oracle and the kernels evaluate sqrt(2 (tb - tb^2/2) kBT/cs2 b[a]) sqrt|rho| (3 roots per site instead of 31; both
+    sides of the parity tests do, so "GPU == oracle" says nothing about this step).  Over 1e6 random sites, densities from
+    1e-9 to 3 of both signs: (i) the oracle's noise moments ARE the factorised amplitude times the site's normal,
+    operation by operation; (ii) the factorised amplitude is within 2 ulp of the reference's literal expression (three
+    correctly rounded operations against two: 1.5 + 0.75 ulp); (iii) the noise moments therefore within 4 ulp; modes 1-3
+    (:117) are the literal expression in both."""
+    n = 100
+    par = dict(kBT=1e-5, tau_f=0.8, tau_g=0.6)
+    p = ob.default_params(**par)
+    rng = np.random.default_rng(11)
+    hbar = np.zeros((15, n, n, n))
+    for c in (0, 1):
+        hbar[c] = 10.0 ** rng.uniform(-9, np.log10(3.0), (n, n, n)) * rng.choice([-1.0, 1.0], (n, n, n), p=[0.1, 0.9])
+    fn = np.zeros((19, n, n, n)); gn = np.zeros_like(fn)
+    ob.lib().orc_thermal_noise(ctypes.byref(p), n, n, n, ob._p(hbar), ctypes.c_uint32(5), ob._p(fn), ob._p(gn))
+    nrm = np.empty((n ** 3, 36))
+    out = np.empty(36)
+    site_normals = ob.lib().orc_site_normals
+    for s in range(n ** 3):
+        site_normals(ctypes.c_uint64(p.seed), ctypes.c_uint64(s), ctypes.c_uint32(5), ob._p(out))
+        nrm[s] = out
+    nrm = nrm.reshape(n, n, n, 36)
+    _, _, b = ob.lattice_tables()
+    tb = 1.0 / (par["tau_f"] + 0.5)
+    base = 2.0 * (tb - 0.5 * (tb * tb)) * par["kBT"]
+    rho, phi = hbar[0], hbar[1]
+    worst_amp = worst_mom = 0.0
+    for a in range(4, 19):
+        for arr, dens, k0 in ((fn, rho, 3), (gn, phi, 18)):
+            z = nrm[..., k0 + (a - 4)]
+            fact = np.sqrt(base / p.cs2 * b[a]) * np.sqrt(np.abs(dens))
+            lit = np.sqrt(base / p.cs2 * b[a] * np.abs(dens))                                # LBM_binary.H:125-126, operation by operation
+            assert np.array_equal(arr[a], fact * z), a                                       # (i)
+            worst_amp = max(worst_amp, float((np.abs(fact - lit) / np.spacing(lit)).max()))  # (ii)
+            ok = z != 0
+            worst_mom = max(worst_mom, float((np.abs(fact * z - lit * z)[ok] / np.spacing(np.abs(lit * z))[ok]).max()))
+    assert worst_amp <= 2.0, worst_amp
+    assert worst_mom <= 4.0, worst_mom
+    for a in (1, 2, 3):
+        lit = np.sqrt(base * np.abs(rho * phi / (rho + phi))) * nrm[..., a - 1]             # :117
+        assert np.array_equal(fn[a], lit) and np.array_equal(gn[a], -lit)
+    assert not fn[0].any() and not gn[0].any()
+
+
 def test_ref_state_branch_of_the_oracle(ob):
     """USE_REF_STATE restatement (LBM_binary.H:92-107): with the current densities as the reference state
     and a zero shift it reproduces the shipped branch bit for bit; a shift of (sx,sy,sz) reads the
