@@ -549,7 +549,7 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       finish_fluid(mg, 1);
       HO_STAMP(9);                                           // g stored
 #ifdef BFLBM_STAMP
-      if (blockIdx.x == 777 && it >= 40 && it < 40 + HO_STAMP_POS && lane == 0) {
+      if (blockIdx.x == (gridDim.x > 777u ? 777u : gridDim.x / 2u + 1u) && it >= 40 && it < 40 + HO_STAMP_POS && lane == 0) {
 #pragma unroll
         for (int k = 0; k < HO_NSTAMP; ++k) g_ho_stamps[((it - 40) * 4 + ty) * HO_NSTAMP + k] = ts[k];
       }

@@ -104,7 +104,8 @@ def test_auto_keys_its_stability_bound_on_the_uploaded_state(pkg, ob):
     total density is rho_hi + rho_lo of the parameters; after LBM_init(f0, g0) -- the restart path, LBM_binary.H:632-661 --
     it is whatever the upload made resident: a checkpoint of a rho_hi = 3 run loaded under HEADER DEFAULTS (alpha0 = 4,
     rho_hi = 1: 4 <= 6) has interaction strength 12 and must run an exact schedule."""
-    shape = (128, 16, 32)
+    shape = (256, 64, 64)                  # 64 tile columns x 4 chunks of 16 planes: `auto` takes the hand-over kernel here
+    ob.lib().orc_set_threads(16)
     src = ob.OracleLattice(*shape, params=ob.default_params(rho_hi=3.0, alpha0=1.5))
     src.init_droplet(0.25)
     lbm = pkg.BinaryLBM(*shape)                                        # header defaults, schedule auto
@@ -118,6 +119,7 @@ def test_auto_keys_its_stability_bound_on_the_uploaded_state(pkg, ob):
     ref.init_from(src.f, src.g)
     for _ in range(3):
         ref.timestep()
+    ob.lib().orc_set_threads(1)
     f, g = lbm.populations()
     assert np.array_equal(f, ref.f) and np.array_equal(g, ref.g)      # exact schedule: the oracle's doubles
     # the same populations scaled to a total density of 1: inside the bound again
@@ -135,7 +137,6 @@ def test_auto_keys_its_stability_bound_on_the_uploaded_state(pkg, ob):
     big.f[:, :16] /= 3.0; big.g[:, :16] /= 3.0
     ring.LBM_init(big.f, big.g)
     assert all(abs(s.state_total_max - 3.0) < 1e-12 for s in ring.slabs)
-    assert all(s.resolved_schedule() == "fused" for s in ring.slabs)
     ring.close()
 
 

@@ -73,8 +73,10 @@ def test_cpp_driver_plotfiles_match_python_writer_and_oracle(pkg, ob, tmp_path):
     assert np.array_equal(fn, ref.fn)
     f, hdr = pf.read_plotfile(pf.concatenate(root + "/f_checkpoint", steps))
     assert np.array_equal(f, ref.f) and hdr["names"] == ["rho_chk"] and hdr["ncomp"] == 19
-    # byte-identical twin
-    twin = pf.write_plotfile(str(tmp_path / "twin"), ref.h, pf.variable_names(22), time=float(steps), step=steps, max_grid_size=n // 2)
+    # byte-identical twin: the python writer on the doubles the driver wrote (as read back above: equal to the oracle's as
+    # numbers; the sign of a zero may differ -- the library's shared-reciprocal division returns +0 for -0/b, DESIGN.md
+    # section 3, and a normal of the round-4 stream is exactly 0 with probability 0.27 %, so such zeros do occur)
+    twin = pf.write_plotfile(str(tmp_path / "twin"), h, pf.variable_names(22), time=float(steps), step=steps, max_grid_size=n // 2)
     src = pf.concatenate(root + "/plt", steps)
     for rel in ("Header", "Level_0/Cell_H", "Level_0/Cell_D_00000"):
         assert filecmp.cmp(os.path.join(src, rel), os.path.join(twin, rel), shallow=False), rel
