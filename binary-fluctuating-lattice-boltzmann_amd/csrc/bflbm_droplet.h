@@ -79,7 +79,26 @@ __global__ void __launch_bounds__(256) k_tanhfit(const double* __restrict__ rho,
   block_sum<kNFit>(v, partial);
 }
 
-// sum the block partials of one launch on the host (fixed order -> deterministic)
+// second stage on the device: one workgroup per plane adds that plane's block partials (fixed order: every thread a strided
+// subsequence, then the tree of block_sum), so that a reduction hands O(nz) doubles to the host instead of one per block --
+// the gradient-flow fit runs ~400 such reductions per fit, at 512^3 that was 8 MB per reduction
+template <int NV>
+__global__ void __launch_bounds__(256) k_sum_partials(const double* __restrict__ partial, double* __restrict__ out, int nbx) {
+  __shared__ double sh[NV][256];
+  double v[NV];
+  for (int k = 0; k < NV; ++k) v[k] = 0.;
+  const long long base = (long long)blockIdx.x * nbx;
+  for (int b = threadIdx.x; b < nbx; b += 256) for (int k = 0; k < NV; ++k) v[k] += partial[(base + b) * NV + k];
+  for (int k = 0; k < NV; ++k) sh[k][threadIdx.x] = v[k];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) for (int k = 0; k < NV; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) for (int k = 0; k < NV; ++k) out[(long long)blockIdx.x * NV + k] = sh[k][0];
+}
+
+// block partials of one launch -> per-plane sums on the device -> summed over the planes on the host (fixed order -> deterministic)
 template <int NV, class Launch>
 int reduce_blocks(bflbm_ctx* c, double (&out)[NV], Launch launch) {
   if (c->step_open) return fail("reduction requested inside an open step");
@@ -88,14 +107,17 @@ int reduce_blocks(bflbm_ctx* c, double (&out)[NV], Launch launch) {
   const dim3 g = plane_grid(c, c->nzl);
   const size_t nblocks = (size_t)g.x * g.y;
   static_assert(NV <= 20, "scratch sizing");
-  double* scratch = c->S[1 - c->cur];               // far larger than nblocks*NV
+  double* scratch = c->S[1 - c->cur];               // far larger than (nblocks + planes)*NV
+  double* planes = scratch + nblocks * NV;
   launch(g, scratch);
   HIP_TRY(hipGetLastError());
-  std::vector<double> h(nblocks * NV);
-  HIP_TRY(hipMemcpyAsync(h.data(), scratch, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL((k_sum_partials<NV>), dim3(g.y), dim3(256), 0, c->stream, scratch, planes, (int)g.x);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> h((size_t)g.y * NV);
+  HIP_TRY(hipMemcpyAsync(h.data(), planes, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (int k = 0; k < NV; ++k) out[k] = 0.;
-  for (size_t b = 0; b < nblocks; ++b) for (int k = 0; k < NV; ++k) out[k] += h[b * NV + k];
+  for (size_t b = 0; b < (size_t)g.y; ++b) for (int k = 0; k < NV; ++k) out[k] += h[b * NV + k];
   return 0;
 }
 
@@ -322,6 +344,20 @@ __global__ void __launch_bounds__(256) k_minmax(const double* __restrict__ rho, 
   }
   if (threadIdx.x == 0) { const long long b = (long long)blockIdx.y * gridDim.x + blockIdx.x; partial[2 * b] = lo[0]; partial[2 * b + 1] = hi[0]; }
 }
+// second stage of k_minmax: one workgroup per plane
+__global__ void __launch_bounds__(256) k_minmax_partials(const double* __restrict__ partial, double* __restrict__ out, int nbx) {
+  __shared__ double lo[256], hi[256];
+  double l = 1e300, h = -1e300;
+  const long long base = (long long)blockIdx.x * nbx;
+  for (int b = threadIdx.x; b < nbx; b += 256) { l = fmin(l, partial[2 * (base + b)]); h = fmax(h, partial[2 * (base + b) + 1]); }
+  lo[threadIdx.x] = l; hi[threadIdx.x] = h;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { lo[threadIdx.x] = fmin(lo[threadIdx.x], lo[threadIdx.x + w]); hi[threadIdx.x] = fmax(hi[threadIdx.x], hi[threadIdx.x + w]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = lo[0]; out[2 * blockIdx.x + 1] = hi[0]; }
+}
 int rho_range(const std::vector<bflbm_ctx*>& ctx, double& lo, double& hi) {
   lo = 1e300; hi = -1e300;
   for (bflbm_ctx* c : ctx) {
@@ -333,10 +369,13 @@ int rho_range(const std::vector<bflbm_ctx*>& ctx, double& lo, double& hi) {
     double* scratch = c->S[1 - c->cur];
     hipLaunchKernelGGL(k_minmax, g, dim3(256), 0, c->stream, c->rho, scratch, c->G, own_lo(c));
     HIP_TRY(hipGetLastError());
-    std::vector<double> h(2 * nb);
-    HIP_TRY(hipMemcpyAsync(h.data(), scratch, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    double* planes = scratch + 2 * nb;
+    hipLaunchKernelGGL(k_minmax_partials, dim3(g.y), dim3(256), 0, c->stream, scratch, planes, (int)g.x);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> h(2 * (size_t)g.y);
+    HIP_TRY(hipMemcpyAsync(h.data(), planes, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (size_t b = 0; b < nb; ++b) { lo = std::min(lo, h[2 * b]); hi = std::max(hi, h[2 * b + 1]); }
+    for (size_t b = 0; b < (size_t)g.y; ++b) { lo = std::min(lo, h[2 * b]); hi = std::max(hi, h[2 * b + 1]); }
   }
   return 0;
 }

@@ -52,8 +52,9 @@
 #define BFLBM_HO_SPREAD_F 28
 #endif
 #ifndef BFLBM_HO_SPREAD_F1
-#define BFLBM_HO_SPREAD_F1 0      // the noise kernel keeps the burst: spacings of 12 ... 60 were all slower
-#endif
+#define BFLBM_HO_SPREAD_F1 44     // noise kernel, round 4: with the 11-instruction normals one request every 44 VALU instructions is
+#endif                            // +2.3 % at 512^3 and +2.0 % at 256^3 (16 ... 32: -1 %, 56: 0, 68: +2.5 / +0.5 %); round 3's generator: every spacing lost
+
 
 // Diagnostic build (-DBFLBM_STAMP, tools/ho_stamps.py): shader-clock stamps at the phase boundaries of a march position,
 // written by lane 0 of every wave of ONE workgroup for 64 steady-state positions.  Not compiled into the product.
@@ -527,8 +528,9 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       // compute while it waits for queue space.  In the quiet kernel the 19 own loads of the f half are therefore requested
       // one every BFLBM_HO_SPREAD_F (28) VALU instructions of the relaxation of f; the order is pinned with
       // sched_group_barrier (the compiler hoists independent loads to the top of the block otherwise).  512^3: 7817 ->
-      // 8484 and 8250 -> 8442 MLUPS on two boxes, 256^3 +2.5 %; spacings of 20 and 36, all 38 loads spread, and the
-      // noise kernel with any spacing were slower than the burst.
+      // 8484 and 8250 -> 8442 MLUPS on two boxes, 256^3 +2.5 %; spacings of 20 and 36 and all 38 loads spread were slower
+      // than the burst (NOTES.md section 3.1f).  The noise kernel: every spacing lost with round 3's generator; with round 4's
+      // (11 instructions per normal) one request every 44 instructions is +2 % at both sizes (profiles/r04_noise_generator_ab.txt).
       if (spread_f) pull_plane(q + 1, nf, ng, hvn, 1, 1);
       if (MODE == 1) d_relax_generated(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, fn3, NA.sr, ntab, rst, R.cs4);
       else           d_relax<false>(P, mf, r, v_b, Hy.uf, Hy.af, P.inv_tau_f_bar, zn, R.cs4);
@@ -595,8 +597,20 @@ struct HoSig { int pa = -1, pb = -1, lz = -1, nchunks = -1, cstride = -1; long l
   bool same_geometry(const HoSig& o) const { return pa == o.pa && pb == o.pb && lz == o.lz && nchunks == o.nchunks && cstride == o.cstride; } };
 
 // Chunking and workgroup order of one launch over the storage planes [pa, pb) (pair_len > 0: the two boundary plane
-// pairs of a slab, one chunk each).  One workgroup is resident per CU, so a launch runs in rounds of `slots` workgroups
-// and costs about rounds x (planes per chunk + 1) march positions; the chunk count minimises that.
+// pairs of a slab, one chunk each).  One workgroup is resident per CU, so a launch runs in rounds of `slots` workgroups.
+// Cost model (round 4, fitted on chunk-count scans at 256^3 ... 512^3, profiles/r04_chunk_scan.txt):
+//     cost = (rounds + tail) x (planes per chunk + HO_CHUNK_OVERHEAD)
+//   HO_CHUNK_OVERHEAD = 4 march positions per workgroup: two lead-in positions that only pull, and four positions at the
+//     chunk's ends whose ring is pulled (38 more loads per lane) because their frames would need the neighbouring chunk
+//     (the round-3 model charged 1: 448^3 ran 2 chunks of 224 planes in 6.1 -> 7 rounds, 7590 MLUPS; 7 chunks: 7950);
+//   tail = (1 - 1/rounds) / 2: workgroups of different CUs drift apart over a launch, the last round ends ragged and half
+//     a workgroup's duration is lost on average -- less the fewer rounds there are (one round of 256 workgroups starts
+//     and ends together: 256^3 is fastest as ONE round of 256-plane marches, 7660 against 7460 / 7340 / 7150 MLUPS for
+//     2 / 4 / 8 chunks), which is why 512^3 runs better as 16 rounds of 128-plane marches (8435 MLUPS) than as 8 rounds
+//     of 256 (7960-8040).  BFLBM_PLAN_MODEL=3 restores the round-3 model (rounds x (planes + 1)) for A/B runs.
+#ifndef HO_CHUNK_OVERHEAD
+#define HO_CHUNK_OVERHEAD 4.0
+#endif
 static inline void handover_plan(const Geo& G, int pa, int pb, int pair_len, FusedGrid& F) {
   constexpr int TX = 64, TY = BFLBM_HO_TY;
   F.ntx = (G.nx + TX - 1) / TX; F.nty = (G.ny + TY - 1) / TY;
@@ -612,15 +626,17 @@ static inline void handover_plan(const Geo& G, int pa, int pb, int pair_len, Fus
   if (want_env > 0) {
     nchunks = std::min(maxchunks, std::max(1, (want_env + F.ncols - 1) / F.ncols));
   } else {
-    long long best = -1; nchunks = 1;
+    static const int model = [] { const char* e = getenv("BFLBM_PLAN_MODEL"); return e ? atoi(e) : 4; }();
+    double best = -1.; nchunks = 1;
     for (int k = 1; k <= maxchunks; ++k) {
       const int lz = (np + k - 1) / k, chunks = (np + lz - 1) / lz;
       if (chunks != k) continue;
       if (G.zwrap && lz > 256 && k < maxchunks) continue;   // one 512-plane march per column was A/B-tested: -1 %
       const long long total = (long long)F.ncols * chunks, rounds = (total + slots - 1) / slots;
       if (!G.zwrap && rounds < min_slab_rounds && k < maxchunks) continue;
-      const long long cost = rounds * (lz + 1);
-      if (best < 0 || cost < best) { best = cost; nchunks = k; }
+      const double cost = model == 3 ? (double)rounds * (lz + 1)
+                                     : ((double)rounds + 0.5 * (1.0 - 1.0 / (double)rounds)) * ((double)lz + HO_CHUNK_OVERHEAD);
+      if (best < 0. || cost < best) { best = cost; nchunks = k; }
     }
   }
   F.lz = (np + nchunks - 1) / nchunks;

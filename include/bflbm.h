@@ -105,13 +105,17 @@ int bflbm_set_stream(bflbm_ctx* c, void* hip_stream, int external);
  *      (bflbm_state_total_max), AND the frames fit in device memory;
  *      else a bit-exact schedule: 0 with noise, and at zero noise 1, or 0 on lattices too small to give the one-pass kernel
  *      a workgroup per CU.  BFLBM_AUTO_EXACT=1 in the environment keeps auto bit-exact, with and without noise.
- * Schedules 0 and 1 give the CPU reference's doubles (same operation order).  Schedule 3 adds the 19 populations of
- * a tile-ring density in another fixed order: deterministic, run-to-run reproducible, the first step after an init or
- * upload bit-identical, later steps different from the reference by what a one-ulp change of the state does.  Measured
- * against the CPU oracle case by case (tools/ho_stress.py, tests/test_gpu_handover_oracle.py) that equals the oracle's
- * own response to a one-ulp perturbation: inside north_star's tolerance (rho, phi, rho+phi 1e-12 relative, velocities
- * 1e-12 cs absolute) for every stable run, and unbounded where the reference run itself diverges (interaction strength
- * alpha0 (rho_hi + rho_lo) >= 7.5: NaN on the CPU path within tens of steps) -- hence the parameter bound in auto. */
+ * Schedules 0 and 1 give the CPU reference's doubles (same operation order).  Schedule 3 adds the 19 populations of a
+ * tile-ring density in another fixed order: deterministic and run-to-run reproducible.  Its contract (the same
+ * sentence in DESIGN.md, INTEGRATION.md and README.md; one test per clause in tests/test_gpu_handover_oracle.py): the
+ * first step after an init or upload equals the CPU reference path bit for bit; after that rho, phi, rho + phi agree
+ * to 1e-12 relative and the velocities to 1e-12 max(cs, |u|) absolute at every site, except at near-vacuum sites (a
+ * density below 1e-3 of its field's maximum), where the difference is what a one-ulp change of the state does to the
+ * reference itself and the bound holds for the density relative to the field maximum and for the momentum.  Of the 92
+ * oracle comparisons of the test suite 75 meet the strict form at every site; the others are listed with their
+ * unmasked maxima in tests/golden/handover_strict_exceptions.json and held to 10 x the oracle's own one-ulp response.
+ * Where the reference run itself diverges (interaction strength alpha0 x total density >= 7.5: NaN on the CPU path
+ * within tens of steps) nothing bounds the difference -- hence the parameter bound in auto. */
 int bflbm_set_schedule(bflbm_ctx* c, int schedule);
 /* The schedule (0, 1 or 3) the next step of this context will run with its current parameters and lattice. */
 int bflbm_resolved_schedule(const bflbm_ctx* c, int* schedule);
