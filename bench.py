@@ -314,9 +314,10 @@ def work(a):
             # workgroup, and the faces should take the first CU a finishing workgroup frees, not queue behind the next round
             try:
                 opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
-            except (AttributeError, TypeError):
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except Exception:                      # noqa: BLE001 -- an older torch without the option: default priority
+                opts = None
+            kw = {} if opts is None else {"pg_options": opts}
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
         else:
             dist.init_process_group(backend)
         os.environ["BFLBM_SLAB_TRANSPORT"] = "direct" if transport == "rccl-direct" else "staged"

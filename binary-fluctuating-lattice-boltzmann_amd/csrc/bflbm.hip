@@ -427,6 +427,13 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   // multiple of 16 (pitch == nx, same code path).  Most of what such sizes lose against 256^3 is partial
   // tiles, not alignment.  Dense layouts (dplane) are kept for everything that crosses the ABI.
   G.pitch = (G.nx > 16) ? ((G.nx + 15) & ~15) : G.nx;
+  {                                              // tuning override: row pitch in doubles (a multiple of 16, >= nx); see NOTES.md "Round 4"
+    static const int pitch_env = [] { const char* e = getenv("BFLBM_PITCH"); return e ? atoi(e) : 0; }();
+    if (pitch_env > 0) {
+      if (pitch_env < G.nx || (pitch_env & 15)) { delete c; return fail("BFLBM_PITCH must be a multiple of 16 and at least nx"); }
+      G.pitch = pitch_env;
+    }
+  }
   G.plane = (long long)G.pitch * G.ny;
   G.dplane = (long long)G.nx * G.ny;
   // component stride: padded so that the 38 component arrays of a power-of-two lattice do not all start

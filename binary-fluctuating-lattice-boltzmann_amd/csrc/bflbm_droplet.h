@@ -98,7 +98,9 @@ __global__ void __launch_bounds__(256) k_sum_partials(const double* __restrict__
   if (threadIdx.x == 0) for (int k = 0; k < NV; ++k) out[(long long)blockIdx.x * NV + k] = sh[k][0];
 }
 
-// block partials of one launch -> per-plane sums on the device -> summed over the planes on the host (fixed order -> deterministic)
+// block partials of one launch -> per-plane sums on the device -> ADDED to `out` plane by plane on the host.  The caller zeroes
+// `out` once and passes the slabs in order, so the sum runs over the planes of the whole lattice in one fixed sequence whatever
+// the decomposition: a ring gives the same doubles as the single context.
 template <int NV, class Launch>
 int reduce_blocks(bflbm_ctx* c, double (&out)[NV], Launch launch) {
   if (c->step_open) return fail("reduction requested inside an open step");
@@ -116,30 +118,27 @@ int reduce_blocks(bflbm_ctx* c, double (&out)[NV], Launch launch) {
   std::vector<double> h((size_t)g.y * NV);
   HIP_TRY(hipMemcpyAsync(h.data(), planes, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  for (int k = 0; k < NV; ++k) out[k] = 0.;
   for (size_t b = 0; b < (size_t)g.y; ++b) for (int k = 0; k < NV; ++k) out[k] += h[b * NV + k];
   return 0;
 }
 
 int moments_of(const std::vector<bflbm_ctx*>& ctx, double out[kNMom]) {
-  for (int k = 0; k < kNMom; ++k) out[k] = 0.;
-  for (bflbm_ctx* c : ctx) {
-    double m[kNMom];
+  double m[kNMom];
+  for (int k = 0; k < kNMom; ++k) m[k] = 0.;
+  for (bflbm_ctx* c : ctx)
     if (reduce_blocks<kNMom>(c, m, [&](dim3 g, double* scratch) {
           hipLaunchKernelGGL(k_moments, g, dim3(256), 0, c->stream, c->rho, scratch, c->G, own_lo(c)); })) return 1;
-    for (int k = 0; k < kNMom; ++k) out[k] += m[k];
-  }
+  for (int k = 0; k < kNMom; ++k) out[k] = m[k];
   return 0;
 }
 
 int normal_equations(const std::vector<bflbm_ctx*>& ctx, const FitParams& F, double out[kNFit]) {
-  for (int k = 0; k < kNFit; ++k) out[k] = 0.;
-  for (bflbm_ctx* c : ctx) {
-    double m[kNFit];
+  double m[kNFit];
+  for (int k = 0; k < kNFit; ++k) m[k] = 0.;
+  for (bflbm_ctx* c : ctx)
     if (reduce_blocks<kNFit>(c, m, [&](dim3 g, double* scratch) {
           hipLaunchKernelGGL(k_tanhfit, g, dim3(256), 0, c->stream, c->rho, scratch, c->G, own_lo(c), F); })) return 1;
-    for (int k = 0; k < kNFit; ++k) out[k] += m[k];
-  }
+  for (int k = 0; k < kNFit; ++k) out[k] = m[k];
   return 0;
 }
 
@@ -395,12 +394,9 @@ int flow_run(const std::vector<bflbm_ctx*>& ctx, const FlowSeries& S, const doub
     for (int d = 0; d < 3; ++d) P.r0[d] = r0[d];
     P.inv_n[0] = 1. / G.nx; P.inv_n[1] = 1. / G.ny; P.inv_n[2] = 1. / G.nz;
     double m[2] = {0., 0.};
-    for (bflbm_ctx* c : ctx) {
-      double part[2];
-      if (reduce_blocks<2>(c, part, [&](dim3 g, double* scratch) {
+    for (bflbm_ctx* c : ctx)
+      if (reduce_blocks<2>(c, m, [&](dim3 g, double* scratch) {
             hipLaunchKernelGGL(k_flowfit, g, dim3(256), 0, c->stream, c->rho, scratch, c->G, own_lo(c), P); })) return 1;
-      m[0] += part[0]; m[1] += part[1];
-    }
     const double s2w = sqrt(2. * W);
     const double MfW = m[0] * cell / (s2w * s2w * s2w), MfR = m[1] * cell / s2w;
     const double C[2] = { MfW - 0.5 * J.Kw, MfR - 0.5 * J.Kr };

@@ -597,20 +597,11 @@ struct HoSig { int pa = -1, pb = -1, lz = -1, nchunks = -1, cstride = -1; long l
   bool same_geometry(const HoSig& o) const { return pa == o.pa && pb == o.pb && lz == o.lz && nchunks == o.nchunks && cstride == o.cstride; } };
 
 // Chunking and workgroup order of one launch over the storage planes [pa, pb) (pair_len > 0: the two boundary plane
-// pairs of a slab, one chunk each).  One workgroup is resident per CU, so a launch runs in rounds of `slots` workgroups.
-// Cost model (round 4, fitted on chunk-count scans at 256^3 ... 512^3, profiles/r04_chunk_scan.txt):
-//     cost = (rounds + tail) x (planes per chunk + HO_CHUNK_OVERHEAD)
-//   HO_CHUNK_OVERHEAD = 4 march positions per workgroup: two lead-in positions that only pull, and four positions at the
-//     chunk's ends whose ring is pulled (38 more loads per lane) because their frames would need the neighbouring chunk
-//     (the round-3 model charged 1: 448^3 ran 2 chunks of 224 planes in 6.1 -> 7 rounds, 7590 MLUPS; 7 chunks: 7950);
-//   tail = (1 - 1/rounds) / 2: workgroups of different CUs drift apart over a launch, the last round ends ragged and half
-//     a workgroup's duration is lost on average -- less the fewer rounds there are (one round of 256 workgroups starts
-//     and ends together: 256^3 is fastest as ONE round of 256-plane marches, 7660 against 7460 / 7340 / 7150 MLUPS for
-//     2 / 4 / 8 chunks), which is why 512^3 runs better as 16 rounds of 128-plane marches (8435 MLUPS) than as 8 rounds
-//     of 256 (7960-8040).  BFLBM_PLAN_MODEL=3 restores the round-3 model (rounds x (planes + 1)) for A/B runs.
-#ifndef HO_CHUNK_OVERHEAD
-#define HO_CHUNK_OVERHEAD 4.0
-#endif
+// pairs of a slab, one chunk each).  One workgroup is resident per CU, so a launch runs in rounds of `slots` workgroups
+// and costs about rounds x (planes per chunk + 1) march positions; the chunk count minimises that.  Round 4 scanned the
+// chunk count at 256^3 ... 512^3 on two boxes (profiles/r04_chunk_scan.txt): a model fitted on the first box
+// ((rounds + tail) x (planes + 4): 448^3 +5 % with 7 chunks, 512^3 +5 % with 4) changed nothing on the second (every
+// lattice within the +-2 % process-to-process scatter, 512x512x128 2 % SLOWER with its choice), so the rule stays.
 static inline void handover_plan(const Geo& G, int pa, int pb, int pair_len, FusedGrid& F) {
   constexpr int TX = 64, TY = BFLBM_HO_TY;
   F.ntx = (G.nx + TX - 1) / TX; F.nty = (G.ny + TY - 1) / TY;
@@ -626,17 +617,15 @@ static inline void handover_plan(const Geo& G, int pa, int pb, int pair_len, Fus
   if (want_env > 0) {
     nchunks = std::min(maxchunks, std::max(1, (want_env + F.ncols - 1) / F.ncols));
   } else {
-    static const int model = [] { const char* e = getenv("BFLBM_PLAN_MODEL"); return e ? atoi(e) : 4; }();
-    double best = -1.; nchunks = 1;
+    long long best = -1; nchunks = 1;
     for (int k = 1; k <= maxchunks; ++k) {
       const int lz = (np + k - 1) / k, chunks = (np + lz - 1) / lz;
       if (chunks != k) continue;
       if (G.zwrap && lz > 256 && k < maxchunks) continue;   // one 512-plane march per column was A/B-tested: -1 %
       const long long total = (long long)F.ncols * chunks, rounds = (total + slots - 1) / slots;
       if (!G.zwrap && rounds < min_slab_rounds && k < maxchunks) continue;
-      const double cost = model == 3 ? (double)rounds * (lz + 1)
-                                     : ((double)rounds + 0.5 * (1.0 - 1.0 / (double)rounds)) * ((double)lz + HO_CHUNK_OVERHEAD);
-      if (best < 0. || cost < best) { best = cost; nchunks = k; }
+      const long long cost = rounds * (lz + 1);
+      if (best < 0 || cost < best) { best = cost; nchunks = k; }
     }
   }
   F.lz = (np + nchunks - 1) / nchunks;
