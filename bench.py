@@ -359,6 +359,7 @@ def work(a):
         barrier()
 
         eng_schedule = eng.resolved_schedule() if hasattr(eng, "resolved_schedule") else a.schedule    # what auto resolves to
+        placement = eng.placement_report() if hasattr(eng, "placement_report") else None
         # EXACTLY a.steps steps per timed block, each block bracketed by barrier + device synchronisation on both sides and
         # reduced with MAX over the ranks; the block is repeated a.blocks times and the MEDIAN block is the reported one
         # (boxes of the pool, and runs on one box, scatter by a few percent: `spread` shows the blocks).
@@ -434,7 +435,7 @@ def work(a):
         return {
             "value": round(sites * a.steps / wall / 1e6, 1), "ms_per_step": round(wall / a.steps * 1e3, 4),
             "workload": workload, "schedule": schedule, "slab_per_gpu": f"{nx}x{ny}x{nz // world}", "spread": spread,
-            "mass_check": [rho_sum, phi_sum], "halo_bytes_per_face": halo_bytes, "halo_transport": tr_text,
+            "mass_check": [rho_sum, phi_sum], "halo_bytes_per_face": halo_bytes, "halo_transport": tr_text, "placement": placement,
             "halo_overlap": None if seq_ms is None else {"ms_per_step_overlapped": round(wall / a.steps * 1e3, 4),
                                                           "ms_per_step_exchange_after_sweep": round(seq_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -460,7 +461,7 @@ def work(a):
     also = {}
 
     def add_also(r):
-        also[r["workload"]] = {k: r[k] for k in ("value", "ms_per_step", "spread", "schedule", "roofline", "halo_overlap", "slab_per_gpu") if r.get(k) is not None}
+        also[r["workload"]] = {k: r[k] for k in ("value", "ms_per_step", "spread", "schedule", "roofline", "halo_overlap", "slab_per_gpu", "placement") if r.get(k) is not None}
     if not explicit and world == 1:
         add_also(run_case(256, 256, 256))
     res = run_case(*head)
@@ -483,7 +484,7 @@ def work(a):
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
                        "mass_check": res["mass_check"], "halo_bytes_per_face": res["halo_bytes_per_face"],
                        "halo_transport": res["halo_transport"],
-                       "halo_overlap": res["halo_overlap"], "also": also or None},
+                       "halo_overlap": res["halo_overlap"], "placement": res["placement"], "also": also or None},
             "roofline": res["roofline"],
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -74,6 +74,9 @@ SIGNATURES = {
     "bflbm_ring_set_overlap": (ctypes.c_int, [_vp, ctypes.c_int]),
     "bflbm_ring_set_transport": (ctypes.c_int, [_vp, ctypes.c_int]),
     "bflbm_ring_last_transport": (ctypes.c_int, [_vp, _P(ctypes.c_int), _P(ctypes.c_int)]),
+    "bflbm_debug_addresses": (ctypes.c_int, [_vp, _P(ctypes.c_ulonglong)]),
+    "bflbm_tune_placement": (ctypes.c_int, [_vp, ctypes.c_int, _P(ctypes.c_float), _P(ctypes.c_int)]),
+    "bflbm_placement_report": (ctypes.c_int, [_vp, _P(ctypes.c_float), _P(ctypes.c_int), _P(ctypes.c_int)]),
     "bflbm_state_total_max": (ctypes.c_int, [_vp, _dp]),
     "bflbm_set_state_total_max": (ctypes.c_int, [_vp, ctypes.c_double]),
     "bflbm_step_boundary": (ctypes.c_int, [_vp]),

@@ -107,6 +107,8 @@ struct bflbm_ctx {
   HoSig fsig[2][2];              // [state buffer][0 interior sweep, 1 boundary pairs]: the launch that wrote the frames
   bool step_open = false;
   double total_max = -1.;        // largest |rho + phi| of the state an upload made resident (< 0: analytic init, the parameters say it)
+  float tune_ms[4] = {0.f, 0.f, 0.f, 0.f};   // bflbm_tune_placement: step time of every candidate allocation tried, and which was kept
+  int tune_n = 0, tune_kept = 0;
   bool density_valid = false;   // rho/phi arrays hold the densities of the resident state
   size_t bytes = 0;
   // USE_REF_STATE (LBM_binary.H:12, :92-107): noise amplitudes from an equilibrium state
@@ -215,7 +217,7 @@ int launch_fused(bflbm_ctx* c, int pa, int pb, int pair_len = 0) {
 
 // The range of model parameters inside which `auto` uses the hand-over kernel.  Schedule 3 differs from the reference's
 // doubles by a re-ordered sum of 19 numbers at tile-edge sites, i.e. by what a one-ulp change of the state does, and
-// what becomes of that is the trajectory's own conditioning: measured against the oracle (tools/ho_stress.py, DESIGN.md
+// what becomes of that is the trajectory's own conditioning: measured against the oracle (tools/ho_stress.py, NOTES.md
 // section 3.1c) the difference equals the oracle's own response to a one-ulp perturbation case by case, which is inside
 // the north-star tolerance wherever the reference run is stable and unbounded where the reference itself diverges
 // (alpha0 = 4 with rho_hi = 3: NaN within 10-40 steps on the CPU path too).  Those diverging runs all have an
@@ -231,7 +233,7 @@ inline bool handover_contract_params(const bflbm_ctx* c) {
   return std::fabs(p.alpha0) * total <= 6.0;       // false for NaN
 }
 
-// Where `auto` expects schedule 3 to be the faster one (A/B on MI355X, tools/ragged_ab.sh):
+// Where `auto` expects schedule 3 to be the faster one (A/B on MI355X, tools/ragged_ab.sh, NOTES.md section 3.1d):
 // it needs marches of at least 16 planes per workgroup (64^3: 16 tile columns cut into chunks of 4 planes, of whose 6
 // positions only 2 read frames: -13 %; 64 x 64 x 256 and 128 x 128 x 64, chunks of 16: equal or better), and at zero
 // noise, where the alternative is the one-pass schedule 1, a last tile column that is not mostly idle lanes (96^3: 75 %
@@ -254,7 +256,7 @@ inline bool handover_worthwhile(const bflbm_ctx* c, bool noisy) {
 // Which bit-exact schedule `auto` takes at zero noise.  The one-pass kernel needs a workgroup per CU to be worth its two
 // planes of look-ahead per chunk: a lattice whose tile columns x 2-plane chunks do not fill the device runs the two-pass
 // schedule faster (same doubles): 32^3 2440 against 1000 MLUPS, 48^3 5070 / 3350, the reference's 8 x 256 x 64 flat-interface
-// box 5910 / 3530; 64^3 (exactly 256 workgroups) and 96^3 are equal (tools/size_sweep.sh).
+// box 5910 / 3530; 64^3 (exactly 256 workgroups) and 96^3 are equal (tools/size_sweep.sh, NOTES.md section 3.1d).
 inline int exact_quiet_schedule(const bflbm_ctx* c) {
   const int lo = c->G.H, hi = c->G.H + c->nzl;
   const int a = c->G.zwrap ? lo : lo + 2, b = c->G.zwrap ? hi : hi - 2;   // the interior sweep
@@ -476,10 +478,95 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   hipMemsetAsync(c->rho, 0, fbytes, c->stream);
   hipMemsetAsync(c->phi, 0, fbytes, c->stream);
   HIP_TRY(hipStreamSynchronize(c->stream));
+  // draw the physical placement again where it pays (see bflbm_tune_placement): lattices of at least 128^3 sites per slab, where
+  // a step is long enough to time; BFLBM_PLACEMENT_CANDIDATES=1 switches it off.  A failure here is not a failure to create.
+  static const int ncand = [] { const char* e = getenv("BFLBM_PLACEMENT_CANDIDATES"); return e ? atoi(e) : 3; }();
+  if (ncand > 1 && (long long)G.nx * G.ny * c->nzl >= (1LL << 21)) (void)bflbm_tune_placement(c, ncand, nullptr, nullptr);
   *out = c;
   return 0;
 }
 
+// ---- physical placement of the state ------------------------------------------------------------------------------
+// Round 4 finding (profiles/r04_level_probe.txt): the step time of a context sits on one of a few discrete levels up to 8 % apart
+// (512^3: 7840 ... 8510 MLUPS), the level belongs to the ALLOCATION -- stable over every block of steps and over a re-init,
+// different from one context to the next at IDENTICAL virtual addresses, alternating deterministically when a process frees
+// and re-creates the context -- i.e. to the physical pages behind it, which the library cannot choose.  It can draw again:
+// time a few steps of the real step kernel on an analytic state, allocate another candidate WHILE HOLDING the first (so that
+// the allocator hands out other memory), time it the same way, keep the faster.  (Round 3 tried this with a pull-copy on the
+// zeroed, fresh buffers as the yardstick, which did not predict the level; the step kernel on an initialised state does.)
+static int probe_ms(bflbm_ctx* c, float* ms) {
+  if (bflbm_init_stripe(c, 0.5)) return 1;
+  const int warm = 2, timed = 4;
+  for (int s = 0; s < warm + timed; ++s) {
+    if (s == warm) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // a slab's faces are not exchanged here: its halo planes keep the analytic state, which changes what is computed next to
+    // the faces and nothing about the time
+    if (bflbm_step_boundary(c) || bflbm_step_interior(c) || bflbm_step_finish(c)) return 1;
+  }
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  *ms /= timed;
+  return 0;
+}
+
+int bflbm_tune_placement(bflbm_ctx* c, int max_candidates, float* ms_per_step, int* kept) {
+  if (!c) return fail("null context");
+  if (c->step_open) return fail("bflbm_tune_placement inside an open step");
+  if (max_candidates < 1 || max_candidates > 4) return fail("max_candidates must be 1 ... 4");
+  HIP_TRY(hipSetDevice(c->dom.device));
+  const Geo& G = c->G;
+  const size_t sdoubles = (size_t)2 * Q * G.vol;
+  const size_t state_bytes = (sdoubles + (size_t)(c->S[1] - c->S[0])) * sizeof(double);     // A, the displacement, B
+  float best_ms = 0.f;
+  if (probe_ms(c, &best_ms)) return 1;
+  if (ms_per_step) ms_per_step[0] = best_ms;
+  c->tune_ms[0] = best_ms; c->tune_n = 1;
+  int best = 0;
+  const size_t fbytes = c->frames[0] ? 2 * handover_frame_doubles(G) * sizeof(double) : 0;
+  for (int k = 1; k < max_candidates; ++k) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < (double)(state_bytes + fbytes) * 1.05) break;   // no room for a second candidate
+    double* oldS[2] = { c->S[0], c->S[1] };
+    double* oldF[2] = { c->frames[0], c->frames[1] };
+    double* nS = nullptr; double* nF = nullptr;
+    if (hipMalloc((void**)&nS, state_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    if (fbytes && hipMalloc((void**)&nF, fbytes) != hipSuccess) { (void)hipGetLastError(); hipFree(nS); break; }
+    c->S[0] = nS; c->S[1] = nS + (oldS[1] - oldS[0]);
+    if (fbytes) { c->frames[0] = nF; c->frames[1] = nF + handover_frame_doubles(G); }
+    c->cur = 0;
+    hipMemsetAsync(nS, 0, state_bytes, c->stream);
+    float ms = 0.f;
+    const int rc = probe_ms(c, &ms);
+    if (ms_per_step) ms_per_step[k] = rc ? -1.f : ms;
+    if (k < 4) { c->tune_ms[k] = rc ? -1.f : ms; c->tune_n = k + 1; }
+    if (!rc && ms < best_ms * 0.995f) {              // keep the new one
+      hipFree(oldS[0]); if (oldF[0]) hipFree(oldF[0]);
+      best_ms = ms; best = k;
+    } else {                                        // keep the old one
+      (void)hipStreamSynchronize(c->stream);
+      hipFree(nS); if (nF) hipFree(nF);
+      c->S[0] = oldS[0]; c->S[1] = oldS[1]; c->frames[0] = oldF[0]; c->frames[1] = oldF[1];
+      if (rc) return 1;
+    }
+  }
+  // back to the state of a fresh context: zeroed buffers (halo planes must never hold garbage), nothing resident
+  HIP_TRY(hipMemsetAsync(c->S[0], 0, state_bytes, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->cur = 0; c->steps = 0; c->density_valid = false; c->step_open = false; c->com_valid = false; c->total_max = -1.;
+  c->ref_kind = 0; c->ref_kind_step = -1;
+  for (auto& b : c->fsig) for (auto& sg : b) sg = HoSig();
+  if (kept) *kept = best;
+  c->tune_kept = best;
+  return 0;
+}
+
+int bflbm_placement_report(const bflbm_ctx* c, float ms_per_step[4], int* tried, int* kept) {
+  if (!c || !ms_per_step || !tried || !kept) return fail("null argument");
+  for (int k = 0; k < 4; ++k) ms_per_step[k] = c->tune_ms[k];
+  *tried = c->tune_n; *kept = c->tune_kept;
+  return 0;
+}
 int bflbm_destroy(bflbm_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->dom.device);
@@ -1022,6 +1109,15 @@ int bflbm_debug_time_kernel(bflbm_ctx* c, int which, int reps, float* ms) {
   return 0;
 }
 
+
+// diagnostics (tools/level_probe.py): device addresses of the state buffers A and B, the density arrays, the reduction scratch
+// and the two frame buffers (0 when not allocated)
+int bflbm_debug_addresses(const bflbm_ctx* c, unsigned long long out[8]) {
+  if (!c || !out) return fail("null argument");
+  out[0] = (unsigned long long)c->S[0]; out[1] = (unsigned long long)c->S[1]; out[2] = (unsigned long long)c->rho; out[3] = (unsigned long long)c->phi;
+  out[4] = (unsigned long long)c->partial; out[5] = (unsigned long long)c->frames[0]; out[6] = (unsigned long long)c->frames[1]; out[7] = (unsigned long long)c->G.vol;
+  return 0;
+}
 
 int bflbm_device_bytes(const bflbm_ctx* c, size_t* bytes) {
   if (!c || !bytes) return fail("null argument");

@@ -124,7 +124,7 @@ __device__ __forceinline__ double ho_shl(double v) {   // value of lane+1 (trave
 // before fluid f is relaxed, the g half after it is finished -- so that memory latency runs under the arithmetic
 // inside one wave instead of between waves.  (At two waves per SIMD the frame producer spills 59-90 registers; that
 // form, and the variants that kept the f plane in registers or requested the next plane before the density sums,
-// were measured and removed: DESIGN.md section 3.1b.)
+// were measured and removed: NOTES.md section 3.1b.)
 // MODE 0: zero noise; MODE 1: generated thermal noise (csrc/bflbm_rng.h), drawn where it is added.
 // RAG: the lattice has a narrower last tile column and/or a lower last tile row (see the header comment)
 template <int TY, int MODE, bool RAG>

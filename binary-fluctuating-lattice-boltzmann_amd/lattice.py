@@ -251,6 +251,19 @@ class BinaryLBM(_DropletMixin):
         """Absolute step of the resident state = noise index of the next step (restart from a kBT > 0 checkpoint)."""
         check(self.lib.bflbm_set_step_count(self._h, int(n)))
 
+    def placement_report(self):
+        """What the placement tuning at creation measured (bflbm_tune_placement): ms per step of every candidate allocation
+        tried and the index of the one kept; None when the context was never tuned (small lattices, BFLBM_PLACEMENT_CANDIDATES=1)."""
+        ms = (ctypes.c_float * 4)()
+        n, k = ctypes.c_int(), ctypes.c_int()
+        check(self.lib.bflbm_placement_report(self._h, ms, ctypes.byref(n), ctypes.byref(k)))
+        return None if n.value == 0 else {"candidates_ms_per_step": [round(float(v), 4) for v in list(ms)[:n.value]], "kept": k.value}
+
+    def tune_placement(self, max_candidates=3):
+        """Draw the physical placement of the state again (leaves the context as freshly created: call before an init)."""
+        check(self.lib.bflbm_tune_placement(self._h, int(max_candidates), None, None))
+        return self.placement_report()
+
     @property
     def state_total_max(self):
         """Largest |rho + phi| of the state the last LBM_init(f0, g0) made resident (what `auto` keys its stability bound

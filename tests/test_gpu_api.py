@@ -171,3 +171,42 @@ print("ok")
 """ % root
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BFLBM_DEBUG_FRAMES_LIMIT="1"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_placement_tuning_leaves_a_fresh_context_and_the_same_doubles(pkg, ob):
+    """bflbm_create draws the physical placement of the state again for slabs of at least 2^21 sites (best of 3 candidate
+    allocations, timed with the context's own step kernel); bflbm_tune_placement does the same on request.  Whatever it
+    keeps, the context is as freshly created and the results are the exact schedules' doubles."""
+    lbm = pkg.BinaryLBM(128, 128, 128, schedule="fused")                # 2^21 sites: tuned at creation
+    rep = lbm.placement_report()
+    assert rep is not None and 1 <= len(rep["candidates_ms_per_step"]) <= 3 and 0 <= rep["kept"] < len(rep["candidates_ms_per_step"])
+    assert all(ms > 0 for ms in rep["candidates_ms_per_step"])
+    assert rep["candidates_ms_per_step"][rep["kept"]] <= min(rep["candidates_ms_per_step"]) * 1.006
+    assert lbm.steps_done == 0 and lbm.state_total_max < 0
+    ob.lib().orc_set_threads(16)
+    ref = ob.OracleLattice(128, 128, 128)
+    ref.init_droplet(0.2)
+    lbm.LBM_init_droplet(0.2)
+    for _ in range(2):
+        ref.timestep()
+    ob.lib().orc_set_threads(1)
+    lbm.LBM_timestep(2)
+    f, g = lbm.populations()
+    assert np.array_equal(f, ref.f) and np.array_equal(g, ref.g)
+    lbm.close()
+    small = pkg.BinaryLBM(16, 16, 16)                                   # below the threshold: not tuned unless asked
+    assert small.placement_report() is None
+    small.LBM_init_stripe(0.5); small.LBM_timestep(3)
+    rep = small.tune_placement(2)
+    assert rep is not None and small.steps_done == 0
+    small.LBM_init_stripe(0.5); small.LBM_timestep(3)
+    r2 = ob.OracleLattice(16, 16, 16); r2.init_stripe(0.5)
+    for _ in range(3):
+        r2.timestep()
+    f, g = small.populations()
+    assert np.array_equal(f, r2.f) and np.array_equal(g, r2.g)
+    small.close()
+    # a slab of a decomposed lattice is tuned without its neighbours (faces not exchanged during the probe)
+    slab = pkg.BinaryLBM(128, 128, 256, z0=0, z1=128, rank=0, nranks=2)
+    assert slab.placement_report() is not None and slab.steps_done == 0
+    slab.close()

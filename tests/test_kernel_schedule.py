@@ -1,7 +1,7 @@
 """The compiled schedule of the hand-over kernel (no GPU needed: hipcc cross-compiles gfx950).
 
 With one wave per SIMD nothing hides a conservative wait, and two faults of exactly that kind were found in the
-generated code of this kernel ("Two faults in the generated schedule"): a `vmcnt(0)` at the
+generated code of this kernel (NOTES.md section 3.1b, "Two faults in the generated schedule"): a `vmcnt(0)` at the
 head of the march loop that drained the stores of every position, and a pulled ring scheduled as 38 load-wait-add
 triples.  Neither shows in the source, so the properties are pinned on the assembly here."""
 import os
@@ -62,7 +62,7 @@ def test_handover_kernel_schedule(device_asm, mode):
 
 
 def test_quiet_kernel_requests_the_f_half_between_the_arithmetic(device_asm):
-    """Round 3: a lone wave that issues 19 requests back to back stands at the issue for as long as
+    """Round 3 (NOTES.md section 3.1f): a lone wave that issues 19 requests back to back stands at the issue for as long as
     the request queue takes to make room; the quiet kernel therefore requests the f half of the next plane one load every
     30 VALU instructions of the relaxation (sched_group_barrier).  Left to itself the compiler hoists the loads into one
     burst again, so the spacing is pinned here: at least 15 loads of the steady-state loop are followed by 20 or more VALU

@@ -6,7 +6,7 @@ this model do: with rho_lo = 0 the minority fluid of a bath is a sum of 19 popul
 at |u| ~ 100 lattice units next to a fresh interface), its density changes sign, and u = j / rho is guarded by
 `abs(rho) > FLT_EPSILON` (LBM_binary.H:246-247).  The ORACLE itself answers a change of one ulp in its initial
 populations with element-wise relative errors of 6e-12 in such densities and 1e-11 in such velocities within 10 steps,
-while everything below stays at 1e-15 (tools/ho_stress.py).  The metric therefore is:
+while everything below stays at 1e-15 (tools/ho_stress.py, NOTES.md section 3.1c).  The metric therefore is:
 
   densities rho, phi, rho+phi   max |d| / max |field|                                       (everywhere)
                                 |d| / |value| at sites where |value| >= 1e-3 max |field|    (where there is fluid)

@@ -1,5 +1,5 @@
 // Calibration-only kernels (not part of the product library): pull-copy variants used to measure the practical
-// bandwidth ceiling of the access pattern (profiles/r01_calibrate_*.json).  Build them into a
+// bandwidth ceiling of the access pattern (profiles/r01_calibrate_*.json, NOTES.md section 3.1).  Build them into a
 // diagnostic library with  make CXXFLAGS+=' -DBFLBM_CALIBRATION'  (csrc/bflbm.hip includes this file then).
 // calibration only: the same pull-copy with two x-adjacent sites per thread (16-byte accesses where aligned)
 __global__ void __launch_bounds__(256) k_pull2(const double* __restrict__ S, double* __restrict__ N, Geo G, int p0) {
