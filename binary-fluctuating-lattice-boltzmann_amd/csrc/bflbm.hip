@@ -480,7 +480,7 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   HIP_TRY(hipStreamSynchronize(c->stream));
   // draw the physical placement again where it pays (see bflbm_tune_placement): lattices of at least 128^3 sites per slab, where
   // a step is long enough to time; BFLBM_PLACEMENT_CANDIDATES=1 switches it off.  A failure here is not a failure to create.
-  static const int ncand = [] { const char* e = getenv("BFLBM_PLACEMENT_CANDIDATES"); return e ? atoi(e) : 3; }();
+  static const int ncand = [] { const char* e = getenv("BFLBM_PLACEMENT_CANDIDATES"); return e ? std::min(atoi(e), 4) : 4; }();
   if (ncand > 1 && (long long)G.nx * G.ny * c->nzl >= (1LL << 21)) (void)bflbm_tune_placement(c, ncand, nullptr, nullptr);
   *out = c;
   return 0;
@@ -492,8 +492,11 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
 // different from one context to the next at IDENTICAL virtual addresses, alternating deterministically when a process frees
 // and re-creates the context -- i.e. to the physical pages behind it, which the library cannot choose.  It can draw again:
 // time a few steps of the real step kernel on an analytic state, allocate another candidate WHILE HOLDING the first (so that
-// the allocator hands out other memory), time it the same way, keep the faster.  (Round 3 tried this with a pull-copy on the
-// zeroed, fresh buffers as the yardstick, which did not predict the level; the step kernel on an initialised state does.)
+// the allocator hands out other memory), time it the same way, keep the faster (only the best so far and the candidate being
+// timed are ever held: twice the state at the peak).  Measured process by process on one box (profiles/r04_placement_ab.txt):
+// 256^3 7580-7910 -> 7900-8110 MLUPS, 384^3 7610 -> 7905, 512^3 7940-8455 -> 8420-8490; the probe's time is the bench's time.
+// (Round 3 tried this with a pull-copy on the zeroed, fresh buffers as the yardstick, which did not predict the level; the
+// step kernel on an initialised state does.)
 static int probe_ms(bflbm_ctx* c, float* ms) {
   if (bflbm_init_stripe(c, 0.5)) return 1;
   const int warm = 2, timed = 4;

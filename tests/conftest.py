@@ -8,6 +8,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# The library draws the physical placement of a context's state again at creation (bflbm_tune_placement: up to four candidate
+# allocations, a few timed steps each) for slabs of at least 2^21 sites.  It changes no result, and the suite creates hundreds of
+# such contexts: switched off here to keep the GPU suite short.  tests/test_gpu_api.py tunes explicitly, and the bench rehearsal
+# of tests/test_gpu_slabs.py runs with the automatic tuning on.
+os.environ.setdefault("BFLBM_PLACEMENT_CANDIDATES", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

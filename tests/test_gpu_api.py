@@ -177,9 +177,9 @@ def test_placement_tuning_leaves_a_fresh_context_and_the_same_doubles(pkg, ob):
     """bflbm_create draws the physical placement of the state again for slabs of at least 2^21 sites (best of 3 candidate
     allocations, timed with the context's own step kernel); bflbm_tune_placement does the same on request.  Whatever it
     keeps, the context is as freshly created and the results are the exact schedules' doubles."""
-    lbm = pkg.BinaryLBM(128, 128, 128, schedule="fused")                # 2^21 sites: tuned at creation
-    rep = lbm.placement_report()
-    assert rep is not None and 1 <= len(rep["candidates_ms_per_step"]) <= 3 and 0 <= rep["kept"] < len(rep["candidates_ms_per_step"])
+    lbm = pkg.BinaryLBM(128, 128, 128, schedule="fused")                # 2^21 sites: tuned at creation unless the environment says no
+    rep = lbm.placement_report() or lbm.tune_placement(4)               # (tests/conftest.py switches the automatic tuning off to keep the suite short)
+    assert rep is not None and 1 <= len(rep["candidates_ms_per_step"]) <= 4 and 0 <= rep["kept"] < len(rep["candidates_ms_per_step"])
     assert all(ms > 0 for ms in rep["candidates_ms_per_step"])
     assert rep["candidates_ms_per_step"][rep["kept"]] <= min(rep["candidates_ms_per_step"]) * 1.006
     assert lbm.steps_done == 0 and lbm.state_total_max < 0
@@ -208,5 +208,6 @@ def test_placement_tuning_leaves_a_fresh_context_and_the_same_doubles(pkg, ob):
     small.close()
     # a slab of a decomposed lattice is tuned without its neighbours (faces not exchanged during the probe)
     slab = pkg.BinaryLBM(128, 128, 256, z0=0, z1=128, rank=0, nranks=2)
-    assert slab.placement_report() is not None and slab.steps_done == 0
+    rep = slab.placement_report() or slab.tune_placement(2)
+    assert rep is not None and slab.steps_done == 0
     slab.close()

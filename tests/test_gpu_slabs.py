@@ -207,18 +207,11 @@ def _bench(args, env=None, timeout=900):
     return json.loads(line[0]), out.stderr
 
 
-@pytest.mark.parametrize("transport,text", [("rccl", "rccl, staged"), ("rccl-direct", "rccl, direct"),
-                                            ("peer-kernel", "a gather kernel reads"), ("peer-copy", "copy engine")])
-def test_bench_two_slabs_on_one_gpu_every_transport(transport, text):
-    """The N > 1 bench path with the hand-over schedule (what auto runs on the 512^3 slabs of the real bench) through each
-    halo transport of the launcher's chain: one JSON line with n_gpus 2, the stripe's mass conserved, the halo size and
-    the transport stated, the exchange-after-sweep leg timed."""
-    r, _ = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--shape", "128,16,12", "--schedule", "handover", "--transport", transport])
+def _check_line(r, transport_text):
     assert r["n_gpus"] == 2 and r["config"]["schedule"] == "handover" and r["scaling"] == "weak"
     assert r["config"]["workload"].startswith("128x16x24")
     assert r["config"]["halo_bytes_per_face"] == 38 * 128 * 16 * 8
-    assert text in r["config"]["halo_transport"], r["config"]["halo_transport"]
-    assert [t["transport"] for t in r["config"]["launcher"]["transports_tried"]] == [transport]
+    assert transport_text in r["config"]["halo_transport"], r["config"]["halo_transport"]
     rho, phi = r["config"]["mass_check"]
     assert abs(rho + phi - 128 * 16 * 24) < 1e-6            # rho + phi = rho_hi + rho_lo = 1 at every site of a stripe
     assert len(r["spread"]["blocks_ms_per_step"]) == 3 and r["value"] > 0
@@ -226,24 +219,43 @@ def test_bench_two_slabs_on_one_gpu_every_transport(transport, text):
     assert ov and ov["ms_per_step_exchange_after_sweep"] > 0
 
 
-def test_bench_falls_back_to_fresh_workers_with_the_next_transport():
-    """The first transport's last rank dies before the rendezvous (what an RCCL abort looks like from outside): the
-    supervisors end its peers, start fresh workers with the next transport of the chain, and the line says so."""
-    r, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "128,16,12", "--no-second-transport"], env={"BFLBM_BENCH_FAIL": "rccl:exit"})
+def test_bench_two_slabs_on_one_gpu_default_chain():
+    """The N > 1 bench path with the hand-over schedule (what auto runs on the 512^3 slabs of the real bench) as the driver
+    starts it: the first transport of the chain (rccl, staged) produces the line -- one JSON line with n_gpus 2, the stripe's
+    mass conserved, the halo size and the transport stated, the exchange-after-sweep leg timed -- and the next transport
+    family (the native ring with in-place peer reads, one process) is timed beside it as an informational leg."""
+    r, _ = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--shape", "128,16,12", "--schedule", "handover"])
+    _check_line(r, "rccl, staged")
     tried = r["config"]["launcher"]["transports_tried"]
-    assert [(t["transport"], t["ok"]) for t in tried] == [("rccl", False), ("peer-kernel", True)]
-    assert "a gather kernel reads" in r["config"]["halo_transport"]
-    assert "4 faces by kernel, 0 by copies" in r["config"]["halo_transport"]
-    assert "FAILED" in err
-    rho, phi = r["config"]["mass_check"]
-    assert abs(rho + phi - 128 * 16 * 24) < 1e-6
+    assert [(t["transport"], t["ok"]) for t in tried] == [("rccl", True), ("peer-kernel", True)]
+    second = r["config"]["second_transport"]
+    assert "a gather kernel reads" in second["halo_transport"] and "4 faces by kernel, 0 by copies" in second["halo_transport"]
+    assert second["value"] > 0 and second["halo_overlap"]["ms_per_step_exchange_after_sweep"] > 0
+
+
+def test_bench_falls_back_to_fresh_workers_with_the_next_transports():
+    """rccl: the last rank dies before the rendezvous (what an RCCL abort looks like from outside); peer-kernel: its one worker
+    exits with an error.  The supervisors end what is left, start fresh workers with the next transport each time, the
+    copy-engine ring (the CU-free transport) produces the line, and the remaining family member (rccl, direct: 38
+    plane-sized sends per face) is timed beside it -- so all four transports have run on this GPU between this test and the
+    previous one."""
+    r, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "128,16,12", "--schedule", "handover"],
+                    env={"BFLBM_BENCH_FAIL": "rccl:exit,peer-kernel:exit"})
+    _check_line(r, "copy engine")
+    assert "0 faces by kernel, 4 by copies" in r["config"]["halo_transport"]
+    tried = r["config"]["launcher"]["transports_tried"]
+    assert [(t["transport"], t["ok"]) for t in tried] == [("rccl", False), ("peer-kernel", False), ("peer-copy", True), ("rccl-direct", True)]
+    assert "rccl, direct" in r["config"]["second_transport"]["halo_transport"]
+    assert err.count("FAILED") == 2
 
 
 def test_bench_config3_slab_shape_two_ranks_sharing_the_gpu():
     """configs[3]'s slab shape as bench.py times it under config.also at N = 4: 512x512x128 per rank, droplet r = 0.2,
     `auto` (-> the hand-over kernel in the interior sweep, pulled rings in the boundary pairs); two ranks here."""
-    r, _ = _bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--shape", "512,512,128", "--init", "droplet", "--transport", "rccl", "--blocks", "1"])
+    r, _ = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--shape", "512,512,128", "--init", "droplet", "--transport", "rccl", "--blocks", "1"],
+                  env={"BFLBM_PLACEMENT_CANDIDATES": "2"})                 # with the placement tuning of bflbm_create on, in both ranks
     assert r["config"]["schedule"] == "handover" and r["config"]["slab_per_gpu"] == "512x512x128"
+    assert r["config"]["placement"] and len(r["config"]["placement"]["candidates_ms_per_step"]) >= 1
     rho, phi = r["config"]["mass_check"]
     assert abs(rho + phi - 512 * 512 * 256) < 1e-3
     assert r["config"]["halo_bytes_per_face"] == 38 * 512 * 512 * 8

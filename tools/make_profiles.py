@@ -58,7 +58,7 @@ if __name__ == "__main__":
     tag, key, schedule, kname = sys.argv[1:5]
     src, dst = os.path.join("gpurun_out", tag), "profiles"
     os.makedirs(dst, exist_ok=True)
-    for f in ("kernel_stats.csv", "pmc_summary.txt", "bench.json"):
+    for f in ("kernel_stats.csv", "pmc_summary.txt", "bench.json", "kernel_timed.json"):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
     summary = os.path.join(dst, f"{tag}_pmc_summary.txt")
@@ -66,8 +66,13 @@ if __name__ == "__main__":
     path = os.path.join(dst, "traffic.json")
     t = json.load(open(path)) if os.path.exists(path) else {}
     stats = os.path.join(dst, f"{tag}_kernel_stats.csv")
+    timed = os.path.join(dst, f"{tag}_kernel_timed.json")
+    avg_all = round(kernel_avg_ms(stats, kname.split(",")), 4) if os.path.exists(stats) else None
+    # round 4: the average over the bench's timed launches (tools/trace_timed_avg.py) where the session has one; the --stats
+    # average over ALL launches (placement probes on discarded allocations included) is kept beside it
+    avg = json.load(open(timed))["avg_timed_ms"] if os.path.exists(timed) else avg_all
     t[f"{key}|{schedule}"] = {"hbm_bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b,
-                              "kernel_avg_ms": round(kernel_avg_ms(stats, kname.split(",")), 4) if os.path.exists(stats) else None,
+                              "kernel_avg_ms": avg, "kernel_avg_all_launches_ms": avg_all,
                               "kernel_stats": stats,
                               "source": summary, "kernel": kname,
                               "rule": "median FETCH_SIZE KiB x1024 x2 (gfx950 half-count, calibrated on k_pull/k_density) + median WRITE_SIZE KiB x1024, from the source file alone"}

@@ -14,5 +14,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/grbm -- python3 bench.py --steps 10 --warmup 2 --blocks 1 --no-cpu-baseline "$@" > $out/grbm.log 2>&1
 python3 bench.py --steps 20 --warmup 5 "$@" > $out/bench.json 2> $out/bench.err     # the driver's own invocation shape (K = 20, median of 3 blocks)
 cat $out/trace/*/*kernel_stats.csv > $out/kernel_stats.csv
+case " $* " in *" --noise "*) kn="k_fused_ho<4, 1";; *) kn="k_fused_ho<4, 0";; esac
+python3 tools/trace_timed_avg.py $(ls $out/trace/*/*kernel_trace.csv | head -1) 20 3 "$kn" > $out/kernel_timed.json; cat $out/kernel_timed.json
 python3 tools/pmc_summary.py $out > $out/pmc_summary.txt
 tail -1 $out/bench.json

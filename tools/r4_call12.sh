@@ -1,0 +1,8 @@
+#!/bin/bash
+# Round 4, GPU call 12: the round's profile sessions again (now with the timed-region average of the kernel trace), changed tests.
+tools/profile_round.sh r04_512_handover --size 512 > gpurun_out/r04_512.log 2>&1; tail -2 gpurun_out/r04_512.log | cut -c1-300
+tools/profile_round.sh r04_256_handover --size 256 > gpurun_out/r04_256.log 2>&1; tail -2 gpurun_out/r04_256.log | cut -c1-300
+tools/profile_round.sh r04_512_noise --size 512 --noise > gpurun_out/r04_512n.log 2>&1; tail -2 gpurun_out/r04_512n.log | cut -c1-300
+tools/profile_round.sh r04_256_noise --size 256 --noise > gpurun_out/r04_256n.log 2>&1; tail -2 gpurun_out/r04_256n.log | cut -c1-300
+for t in r04_512_handover r04_256_handover r04_512_noise r04_256_noise; do rm -rf gpurun_out/$t/trace gpurun_out/$t/fetch gpurun_out/$t/write gpurun_out/$t/sq gpurun_out/$t/grbm; done
+timeout -k 10 600 python -m pytest tests/test_gpu_api.py tests/test_gpu_slabs.py -q -m gpu --durations=12 > gpurun_out/r4_call12_pytest.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/r4_call12_pytest.log; tail -22 gpurun_out/r4_call12_pytest.log
