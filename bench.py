@@ -126,6 +126,7 @@ def parse_args():
     ap.add_argument("--transport", default=os.environ.get("BFLBM_BENCH_TRANSPORT_CHAIN", "auto"),
                     help="N > 1: auto (the chain " + " -> ".join(TRANSPORT_CHAIN) + ", first that completes), one of them, or a comma list")
     ap.add_argument("--attempt-timeout", type=float, default=420.0, help="N > 1: wall-clock limit of one transport attempt, seconds")
+    ap.add_argument("--no-overlap-leg", action="store_true", help="N > 1: skip the informational steps with the exchange after the sweep")
     ap.add_argument("--no-second-transport", action="store_true",
                     help="N > 1, --transport auto: do not time the next transport family as an informational leg")
     return ap.parse_args()
@@ -388,7 +389,7 @@ def work(a):
         # N > 1: the same steps with the exchange AFTER the sweep instead of behind it (configs[3]: "overlap
         # efficiency"); outside the timed region, and never allowed to break the headline line
         seq_ms = None
-        if world > 1:
+        if world > 1 and not a.no_overlap_leg:
             try:
                 if use_dist:
                     lat.overlap = False

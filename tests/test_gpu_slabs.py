@@ -252,7 +252,7 @@ def test_bench_falls_back_to_fresh_workers_with_the_next_transports():
 def test_bench_config3_slab_shape_two_ranks_sharing_the_gpu():
     """configs[3]'s slab shape as bench.py times it under config.also at N = 4: 512x512x128 per rank, droplet r = 0.2,
     `auto` (-> the hand-over kernel in the interior sweep, pulled rings in the boundary pairs); two ranks here."""
-    r, _ = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--shape", "512,512,128", "--init", "droplet", "--transport", "rccl", "--blocks", "1"],
+    r, _ = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--shape", "512,512,128", "--init", "droplet", "--transport", "rccl", "--blocks", "1", "--no-overlap-leg"],
                   env={"BFLBM_PLACEMENT_CANDIDATES": "2"})                 # with the placement tuning of bflbm_create on, in both ranks
     assert r["config"]["schedule"] == "handover" and r["config"]["slab_per_gpu"] == "512x512x128"
     assert r["config"]["placement"] and len(r["config"]["placement"]["candidates_ms_per_step"]) >= 1
