@@ -1239,7 +1239,11 @@ int bflbm_ring_create(const bflbm_params* p, const int n[3], int nslabs, const i
     for (int k = 0; k < nslabs && e == hipSuccess; ++k) {
       e = hipSetDevice(r->ctx[k]->dom.device);
       hipStream_t st = nullptr; hipEvent_t e1 = nullptr, e2 = nullptr;
-      if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+      // the comm stream at the device's highest priority: its gather kernels (or copies) should take the first CU a finishing
+      // workgroup of the 512-register interior sweep frees, not queue behind the sweep's next round
+      int prio_lo = 0, prio_hi = 0;
+      if (e == hipSuccess && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { (void)hipGetLastError(); prio_hi = 0; }
+      if (e == hipSuccess) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_hi);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&e2, hipEventDisableTiming);
       r->comm.push_back(st); r->packed.push_back(e1); r->unpacked.push_back(e2);
