@@ -499,17 +499,25 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
 // step kernel on an initialised state does.)
 static int probe_ms(bflbm_ctx* c, float* ms) {
   if (bflbm_init_stripe(c, 0.5)) return 1;
-  const int warm = 2, timed = 4;
-  for (int s = 0; s < warm + timed; ++s) {
-    if (s == warm) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    // a slab's faces are not exchanged here: its halo planes keep the analytic state, which changes what is computed next to
-    // the faces and nothing about the time
-    if (bflbm_step_boundary(c) || bflbm_step_interior(c) || bflbm_step_finish(c)) return 1;
-  }
-  HIP_TRY(hipEventRecord(c->ev1, c->stream));
-  HIP_TRY(hipEventSynchronize(c->ev1));
-  HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
-  *ms /= timed;
+  // a slab's faces are not exchanged here: its halo planes keep the analytic state, which changes what is computed next to the
+  // faces and nothing about the time
+  auto run = [&](int nsteps, float* out) -> int {
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int s = 0; s < nsteps; ++s) if (bflbm_step_boundary(c) || bflbm_step_interior(c) || bflbm_step_finish(c)) return 1;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(out, c->ev0, c->ev1));
+    return 0;
+  };
+  // at least 2 warm-up and 4 timed steps, and at least ~30 ms of warm-up and ~25 ms timed, so that the first candidate of a
+  // fresh context (clocks still ramping after the allocation) is not handicapped on lattices whose step takes 2 ms
+  float t2 = 0.f;
+  if (run(2, &t2)) return 1;
+  const float step = std::max(t2 / 2.f, 1e-3f);
+  const int more_warm = std::max(0, (int)std::ceil(30.f / step) - 2), timed = std::max(4, (int)std::ceil(25.f / step));
+  if (more_warm > 0 && run(std::min(more_warm, 64), &t2)) return 1;
+  if (run(std::min(timed, 64), ms)) return 1;
+  *ms /= (float)std::min(timed, 64);
   return 0;
 }
 
@@ -533,22 +541,26 @@ int bflbm_tune_placement(bflbm_ctx* c, int max_candidates, float* ms_per_step, i
     double* oldS[2] = { c->S[0], c->S[1] };
     double* oldF[2] = { c->frames[0], c->frames[1] };
     double* nS = nullptr; double* nF = nullptr;
-    if (hipMalloc((void**)&nS, state_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-    if (fbytes && hipMalloc((void**)&nF, fbytes) != hipSuccess) { (void)hipGetLastError(); hipFree(nS); break; }
-    c->S[0] = nS; c->S[1] = nS + (oldS[1] - oldS[0]);
-    if (fbytes) { c->frames[0] = nF; c->frames[1] = nF + handover_frame_doubles(G); }
+    // diagnostics (tools/level_probe.py): BFLBM_TUNE_WHAT=state|frames draws only that allocation again (which of the two decides the level?)
+    const char* what_env = getenv("BFLBM_TUNE_WHAT");
+    const bool draw_state = !what_env || strcmp(what_env, "frames") != 0, draw_frames = fbytes && (!what_env || strcmp(what_env, "state") != 0);
+    if (draw_state && hipMalloc((void**)&nS, state_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    if (draw_frames && hipMalloc((void**)&nF, fbytes) != hipSuccess) { (void)hipGetLastError(); if (nS) hipFree(nS); break; }
+    if (draw_state) { c->S[0] = nS; c->S[1] = nS + (oldS[1] - oldS[0]); hipMemsetAsync(nS, 0, state_bytes, c->stream); }
+    if (draw_frames) { c->frames[0] = nF; c->frames[1] = nF + handover_frame_doubles(G); }
     c->cur = 0;
-    hipMemsetAsync(nS, 0, state_bytes, c->stream);
     float ms = 0.f;
     const int rc = probe_ms(c, &ms);
     if (ms_per_step) ms_per_step[k] = rc ? -1.f : ms;
     if (k < 4) { c->tune_ms[k] = rc ? -1.f : ms; c->tune_n = k + 1; }
     if (!rc && ms < best_ms * 0.995f) {              // keep the new one
-      hipFree(oldS[0]); if (oldF[0]) hipFree(oldF[0]);
+      if (draw_state) hipFree(oldS[0]);
+      if (draw_frames && oldF[0]) hipFree(oldF[0]);
       best_ms = ms; best = k;
     } else {                                        // keep the old one
       (void)hipStreamSynchronize(c->stream);
-      hipFree(nS); if (nF) hipFree(nF);
+      if (nS) hipFree(nS);
+      if (nF) hipFree(nF);
       c->S[0] = oldS[0]; c->S[1] = oldS[1]; c->frames[0] = oldF[0]; c->frames[1] = oldF[1];
       if (rc) return 1;
     }
