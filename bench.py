@@ -8,7 +8,7 @@ LBM_binary.H:545-594) over the whole lattice.  N=1: the headline `value` is the 
 noise (stripe init) that BASELINE.json quotes its 60 % target on; configs[1]'s 256^3 is timed in the same run
 and reported, with its own roofline, under config.also.  N>1: weak scaling, every GPU owns a 512x512x512
 z-slab of a 512x512x(512 N) box, +-z planes exchanged and overlapped with the interior planes; at N=4 / N=8 the slab
-shapes of configs[3] (512x512x128, droplet) / configs[4] (1024x1024x64, mixture with kBT > 0) are timed in the same
+shapes of configs[3] (512x512x128, droplet) / configs[4] (1024x1024x64, mixture with kBT > 0, alpha0 = 2.5) are timed in the same
 run under config.also.  --size S / --shape NX,NY,NZ time one explicit case instead.
 Populations are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
@@ -471,7 +471,9 @@ def work(a):
             if world == 4:
                 add_also(run_case(512, 512, 128, init="droplet", noise=False))                # configs[3]: 512^3 droplet on 4 z-slabs
             if world == 8:
-                add_also(run_case(1024, 1024, 64, init="mixture", noise=True, alpha0=4.0))    # configs[4]: 1024x1024x512 spinodal mixture
+                # configs[4]: 1024x1024x512 spinodal mixture.  alpha0 = 2.5: SURVEY 8d's example alpha0 = 4 on the rho = phi = 1 mixture
+                # is NaN within 50 steps on the reference's own CPU path (tests/test_oracle_pins.py); 2.5 demixes and stays finite
+                add_also(run_case(1024, 1024, 64, init="mixture", noise=True, alpha0=2.5))
         except Exception as exc:                       # noqa: BLE001
             print(f"[bench] config.also case skipped: {exc!r}", file=sys.stderr)
 

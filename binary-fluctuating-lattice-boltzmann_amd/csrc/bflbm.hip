@@ -671,7 +671,11 @@ static inline int ext_global_z(const bflbm_ctx* c, int pe) {
 int bflbm_init_mixture(bflbm_ctx* c) {
   if (!c) return fail("null context");
   const double C1 = 0.5, C2 = 0.5;               // LBM_binary.H:606-614
-  return run_init(c, 0, nullptr, 0, 2. * C1, 2. * C2, 0.);
+  if (run_init(c, 0, nullptr, 0, 2. * C1, 2. * C2, 0.)) return 1;
+  // rho = phi = 1 at every site whatever rho_hi / rho_lo say (:613-614): the total density `auto` keys its stability bound on is 2
+  // (alpha0 = 4 on this state is NaN within 50 steps on the reference's CPU path, tests/test_oracle_pins.py)
+  c->total_max = 2. * C1 + 2. * C2;
+  return 0;
 }
 
 int bflbm_init_stripe(bflbm_ctx* c, double frac) {

@@ -132,8 +132,8 @@ int bflbm_init_droplet(bflbm_ctx* c, double r);
 int bflbm_upload_fg(bflbm_ctx* c, const double* f, const double* g, const bflbm_fab* box);
 int bflbm_commit_upload(bflbm_ctx* c, int reset_step_counter);
 /* The total density `auto` keys its stability bound on (bflbm_set_schedule): the largest |rho + phi| of the state the last
- * bflbm_commit_upload made resident (LBM_init, LBM_binary.H:632-661), or a negative number after an analytic init (then
- * rho_hi + rho_lo of the parameters is that number at every site).  A driver that owns several slabs hands each slab the
+ * bflbm_commit_upload made resident (LBM_init, LBM_binary.H:632-661); 2 after LBM_init_mixture (rho = phi = 1 at every site,
+ * :613-614); a negative number after LBM_init_stripe / _droplet (then rho_hi + rho_lo of the parameters is that number at every site).  A driver that owns several slabs hands each slab the
  * maximum over all of them (bflbm_ring_commit_upload does). */
 int bflbm_state_total_max(const bflbm_ctx* c, double* total_max);
 int bflbm_set_state_total_max(bflbm_ctx* c, double total_max);

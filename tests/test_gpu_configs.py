@@ -222,14 +222,21 @@ def test_handover_random_cases(pkg):
 
 
 def test_config4_spinodal_slabs_with_the_default_schedule(pkg):
-    """configs[4] as a user runs it: LBM_init_mixture is homogeneous (LBM_binary.H:613-614), so the "spinodal mixture" is
-    alpha0 = 4 with kBT = 1e-5 seeding the decomposition; two 1024 x 1024 x 64 slabs under `auto` (= the
+    """configs[4] as a user runs it: LBM_init_mixture is homogeneous (LBM_binary.H:613-614), so the "spinodal mixture" is an
+    alpha0 above the demixing threshold with kBT = 1e-5 seeding the decomposition.  SURVEY's example alpha0 = 4
+    is NaN within 50 steps on the reference's own CPU path (rho = phi = 1: total density 2, interaction strength 8;
+    tests/test_oracle_pins.py) and `auto` keeps such a run on an exact schedule; alpha0 = 2.5 demixes into stable domains
+    (rho = 2.23 / 0) and is what runs here: two 1024 x 1024 x 64 slabs under `auto` (= the
     hand-over kernel with the generator inside, in every slab's interior sweep and boundary pairs).  The noise stream is
     a function of the GLOBAL site index, so the first step equals the undecomposed two-pass run bit for bit; after 8
     steps the two agree at the north-star tolerance (metric of tests/tolerances.py); mass is conserved to rounding."""
     import tolerances
     nx, ny, nz = 1024, 1024, 128
-    par = pkg.default_params(kBT=1e-5, alpha0=4.0)
+    par = pkg.default_params(kBT=1e-5, alpha0=2.5)
+    hot = pkg.BinaryLBM(128, 128, 64, params=pkg.default_params(kBT=1e-5, alpha0=4.0))
+    hot.LBM_init_mixture()
+    assert hot.state_total_max == 2.0 and hot.resolved_schedule() == "two_pass"    # 4 x 2 > 6: never the hand-over kernel
+    hot.close()
     out = {}
     for name, make in (("exact", lambda: pkg.BinaryLBM(nx, ny, nz, params=par, schedule="two_pass")),
                        ("slabs", lambda: pkg.RingLBM(nx, ny, nz, nslabs=2, devices=(0,), params=par))):

@@ -325,7 +325,7 @@ def test_auto_stays_exact_when_asked_or_out_of_range(pkg):
     """BFLBM_AUTO_EXACT=1 keeps auto bit-exact with noise too; the parameter bound; frames that do not fit."""
     import subprocess
     code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as ge; pkg = ge.load_package()\n"
-            "a = pkg.BinaryLBM(256, 256, 32, params=pkg.default_params(kBT=1e-5)); b = pkg.BinaryLBM(256, 256, 32)\n"
+            "a = pkg.BinaryLBM(256, 256, 32, params=pkg.default_params(kBT=1e-5, alpha0=2.5)); b = pkg.BinaryLBM(256, 256, 32)\n"
             "a.LBM_init_mixture(); b.LBM_init_stripe(0.5); a.LBM_timestep(2); b.LBM_timestep(2)\n"
             "print(a.resolved_schedule(), b.resolved_schedule())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     def run(env):
@@ -336,6 +336,9 @@ def test_auto_stays_exact_when_asked_or_out_of_range(pkg):
     assert run({"BFLBM_DEBUG_FRAMES_LIMIT": "1"}) == ["two_pass", "fused"]          # allocation of the frames refused: auto falls back
     with pkg.BinaryLBM(256, 256, 32, params=pkg.default_params(alpha0=2.5, rho_hi=3.0)) as l:
         assert l.resolved_schedule() == "fused"
+    with pkg.BinaryLBM(256, 256, 32, params=pkg.default_params(kBT=1e-5)) as l:   # header alpha0 = 4 on the rho = phi = 1 mixture: total
+        l.LBM_init_mixture()                                                       # density 2, strength 8 (NaN on the CPU path within 50 steps)
+        assert l.resolved_schedule() == "two_pass" and l.state_total_max == 2.0
     with pkg.BinaryLBM(256, 256, 32, params=pkg.default_params(alpha0=1.7, rho_hi=3.0)) as l:
         assert l.resolved_schedule() == "handover"
     for shape in ((128, 13, 8), (129, 12, 8)):               # a last tile row / column of ONE site: refused, resolves to the exact schedule

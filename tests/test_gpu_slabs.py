@@ -127,8 +127,19 @@ def _gloo_gpu_worker(rank, world, port, outdir, n, steps, par, staged=False, sch
     f, g = lat.populations()
     np.savez(os.path.join(outdir, f"r{rank}.npz"), f=f, g=g, h=lat.LBM_hydrovars(), z0=lat.z0, z1=lat.z1,
              com=lat.update_com(), mass=np.array(lat.mass()))
+    # restart of a fluctuating run (main_run_job.cpp:80 step_continue, :253-270): a second lattice takes the populations through
+    # LBM_init and the absolute step through set_steps_done, and continues the noise stream where the first one is
+    again = pkg.SlabLattice(*n, params=pkg.default_params(**par), device=torch.device("cuda", 0), schedule=schedule)
+    again.LBM_init(np.ascontiguousarray(f), np.ascontiguousarray(g))
+    again.set_steps_done(steps)
+    assert again.steps_done == steps == lat.steps_done
+    lat.LBM_timestep(2); again.LBM_timestep(2)
+    torch.cuda.synchronize()
+    fc, gc = lat.populations()
+    fr, gr = again.populations()
+    np.savez(os.path.join(outdir, f"restart{rank}.npz"), fc=fc, gc=gc, fr=fr, gr=gr)
     dist.barrier()
-    lat.close()
+    lat.close(); again.close()
     dist.destroy_process_group()
 
 
@@ -158,6 +169,14 @@ def test_distributed_driver_ranks_sharing_one_gpu(ob, world, staged):
             _same(o["h"], ref.h[:, z0:z1], f"rank {r} hydrovs")
             np.testing.assert_allclose(o["com"], ref.com(), rtol=1e-12)
             np.testing.assert_allclose(o["mass"], [ref.hbar[0].sum(), ref.hbar[1].sum()], rtol=1e-12)
+        for _ in range(2):
+            ref.timestep()
+        for r in range(world):                              # the restarted lattice == the uninterrupted one == the oracle
+            o, rs = np.load(os.path.join(d, f"r{r}.npz")), np.load(os.path.join(d, f"restart{r}.npz"))
+            z0, z1 = int(o["z0"]), int(o["z1"])
+            _same(rs["fr"], rs["fc"], f"rank {r} restarted f")
+            _same(rs["gr"], rs["gc"], f"rank {r} restarted g")
+            _same(rs["fc"], ref.f[:, z0:z1], f"rank {r} f after the continuation")
 
 
 def test_distributed_driver_with_the_handover_schedule(ob):

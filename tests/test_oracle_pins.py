@@ -292,6 +292,30 @@ def test_factorised_noise_amplitude_against_the_reference_expression(ob):
     assert not fn[0].any() and not gn[0].any()
 
 
+def test_spinodal_mixture_parameters_of_configs4(ob):
+    """BASELINE configs[4] is a "binary spinodal mixture"; LBM_init_mixture is homogeneous (rho = phi = 1, LBM_binary.H:613-614), so
+    the decomposition is seeded by kBT > 0 at an alpha0 above the demixing threshold.  SURVEY 8d's example alpha0 = 4 does not
+    survive on the reference's own arithmetic: total density 2, interaction strength 8 -- NaN within 50 steps.  alpha0 = 2.5
+    (strength 5, inside `auto`'s bound of 6) demixes into stable domains; that is what bench.py times at N = 8."""
+    ob.lib().orc_set_threads(8)
+    try:
+        hot = ob.OracleLattice(16, 16, 16, params=ob.default_params(kBT=1e-5, alpha0=4.0))
+        hot.init_mixture()
+        for _ in range(50):
+            hot.timestep()
+        assert not np.isfinite(hot.h[:9]).all()
+        ok = ob.OracleLattice(16, 16, 16, params=ob.default_params(kBT=1e-5, alpha0=2.5))
+        ok.init_mixture()
+        m0 = ok.hbar[0].sum()
+        for _ in range(600):
+            ok.timestep()
+        assert np.isfinite(ok.h[:9]).all()
+        assert ok.h[0].max() > 1.8 and ok.h[0].min() < 0.2                 # demixed: domains near rho = 2.2 and 0
+        assert abs(ok.hbar[0].sum() - m0) < 1e-9 * m0
+    finally:
+        ob.lib().orc_set_threads(1)
+
+
 def test_ref_state_branch_of_the_oracle(ob):
     """USE_REF_STATE restatement (LBM_binary.H:92-107): with the current densities as the reference state
     and a zero shift it reproduces the shipped branch bit for bit; a shift of (sx,sy,sz) reads the
