@@ -107,7 +107,7 @@ struct bflbm_ctx {
   HoSig fsig[2][2];              // [state buffer][0 interior sweep, 1 boundary pairs]: the launch that wrote the frames
   bool step_open = false;
   double total_max = -1.;        // largest |rho + phi| of the state an upload made resident (< 0: analytic init, the parameters say it)
-  float tune_ms[4] = {0.f, 0.f, 0.f, 0.f};   // bflbm_tune_placement: step time of every candidate allocation tried, and which was kept
+  float tune_ms[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // bflbm_tune_placement: step time of every candidate allocation tried, and which was kept
   int tune_n = 0, tune_kept = 0;
   bool density_valid = false;   // rho/phi arrays hold the densities of the resident state
   size_t bytes = 0;
@@ -480,7 +480,10 @@ int bflbm_create(const bflbm_params* p, const bflbm_domain* d, bflbm_ctx** out) 
   HIP_TRY(hipStreamSynchronize(c->stream));
   // draw the physical placement again where it pays (see bflbm_tune_placement): lattices of at least 128^3 sites per slab, where
   // a step is long enough to time; BFLBM_PLACEMENT_CANDIDATES=1 switches it off.  A failure here is not a failure to create.
-  static const int ncand = [] { const char* e = getenv("BFLBM_PLACEMENT_CANDIDATES"); return e ? std::min(atoi(e), 4) : 4; }();
+  // Default: 4 candidates, 8 where a candidate is cheap (a state below 24 GB: 256^3 still scattered over 7950 ... 8350 MLUPS with 4,
+  // profiles/r04_knobs_rescan.txt; a probe there takes 60 ms).
+  static const int ncand_env = [] { const char* e = getenv("BFLBM_PLACEMENT_CANDIDATES"); return e ? std::max(1, std::min(atoi(e), 8)) : 0; }();
+  const int ncand = ncand_env > 0 ? ncand_env : (2 * sbytes <= ((size_t)24 << 30) ? 8 : 4);
   if (ncand > 1 && (long long)G.nx * G.ny * c->nzl >= (1LL << 21)) (void)bflbm_tune_placement(c, ncand, nullptr, nullptr);
   *out = c;
   return 0;
@@ -524,7 +527,7 @@ static int probe_ms(bflbm_ctx* c, float* ms) {
 int bflbm_tune_placement(bflbm_ctx* c, int max_candidates, float* ms_per_step, int* kept) {
   if (!c) return fail("null context");
   if (c->step_open) return fail("bflbm_tune_placement inside an open step");
-  if (max_candidates < 1 || max_candidates > 4) return fail("max_candidates must be 1 ... 4");
+  if (max_candidates < 1 || max_candidates > 8) return fail("max_candidates must be 1 ... 8");
   HIP_TRY(hipSetDevice(c->dom.device));
   const Geo& G = c->G;
   const size_t sdoubles = (size_t)2 * Q * G.vol;
@@ -552,7 +555,7 @@ int bflbm_tune_placement(bflbm_ctx* c, int max_candidates, float* ms_per_step, i
     float ms = 0.f;
     const int rc = probe_ms(c, &ms);
     if (ms_per_step) ms_per_step[k] = rc ? -1.f : ms;
-    if (k < 4) { c->tune_ms[k] = rc ? -1.f : ms; c->tune_n = k + 1; }
+    if (k < 8) { c->tune_ms[k] = rc ? -1.f : ms; c->tune_n = k + 1; }
     if (!rc && ms < best_ms * 0.995f) {              // keep the new one
       if (draw_state) hipFree(oldS[0]);
       if (draw_frames && oldF[0]) hipFree(oldF[0]);
@@ -576,9 +579,9 @@ int bflbm_tune_placement(bflbm_ctx* c, int max_candidates, float* ms_per_step, i
   return 0;
 }
 
-int bflbm_placement_report(const bflbm_ctx* c, float ms_per_step[4], int* tried, int* kept) {
+int bflbm_placement_report(const bflbm_ctx* c, float ms_per_step[8], int* tried, int* kept) {
   if (!c || !ms_per_step || !tried || !kept) return fail("null argument");
-  for (int k = 0; k < 4; ++k) ms_per_step[k] = c->tune_ms[k];
+  for (int k = 0; k < 8; ++k) ms_per_step[k] = c->tune_ms[k];
   *tried = c->tune_n; *kept = c->tune_kept;
   return 0;
 }

@@ -254,7 +254,7 @@ class BinaryLBM(_DropletMixin):
     def placement_report(self):
         """What the placement tuning at creation measured (bflbm_tune_placement): ms per step of every candidate allocation
         tried and the index of the one kept; None when the context was never tuned (small lattices, BFLBM_PLACEMENT_CANDIDATES=1)."""
-        ms = (ctypes.c_float * 4)()
+        ms = (ctypes.c_float * 8)()
         n, k = ctypes.c_int(), ctypes.c_int()
         check(self.lib.bflbm_placement_report(self._h, ms, ctypes.byref(n), ctypes.byref(k)))
         return None if n.value == 0 else {"candidates_ms_per_step": [round(float(v), 4) for v in list(ms)[:n.value]], "kept": k.value}

@@ -347,10 +347,10 @@ int bflbm_debug_time_kernel(bflbm_ctx* c, int which, int reps, float* ms_per_lau
 /* Physical placement.  A context's step time sits on one of a few discrete levels up to 8 % apart that belong to the physical
  * pages behind its allocation.  bflbm_tune_placement times a few steps of the context's own step kernel on
  * an analytic state, allocates up to max_candidates - 1 further candidates while holding the best so far, and keeps the fastest;
- * the context is left as freshly created (no state resident).  bflbm_create calls it with 4 candidates for slabs of at least
- * 2^21 sites (BFLBM_PLACEMENT_CANDIDATES=1: never).  ms_per_step (nullable): time of every candidate tried; kept (nullable): its index. */
+ * the context is left as freshly created (no state resident).  bflbm_create calls it with 4 candidates (8 when the state is below
+ * 24 GB) for slabs of at least 2^21 sites (BFLBM_PLACEMENT_CANDIDATES=1: never; max_candidates: 1 ... 8).  ms_per_step (nullable): time of every candidate tried; kept (nullable): its index. */
 int bflbm_tune_placement(bflbm_ctx* c, int max_candidates, float* ms_per_step, int* kept);
-int bflbm_placement_report(const bflbm_ctx* c, float ms_per_step[4], int* tried, int* kept);   /* what the last tuning measured (tried = 0: never tuned) */
+int bflbm_placement_report(const bflbm_ctx* c, float ms_per_step[8], int* tried, int* kept);   /* what the last tuning measured (tried = 0: never tuned) */
 int bflbm_debug_addresses(const bflbm_ctx* c, unsigned long long out[8]);   /* diagnostics: device addresses of the state A, B, rho, phi, scratch, frames x 2; component stride in doubles */
 int bflbm_device_bytes(const bflbm_ctx* c, size_t* bytes);
 

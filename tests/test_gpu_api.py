@@ -179,7 +179,7 @@ def test_placement_tuning_leaves_a_fresh_context_and_the_same_doubles(pkg, ob):
     keeps, the context is as freshly created and the results are the exact schedules' doubles."""
     lbm = pkg.BinaryLBM(128, 128, 128, schedule="fused")                # 2^21 sites: tuned at creation unless the environment says no
     rep = lbm.placement_report() or lbm.tune_placement(4)               # (tests/conftest.py switches the automatic tuning off to keep the suite short)
-    assert rep is not None and 1 <= len(rep["candidates_ms_per_step"]) <= 4 and 0 <= rep["kept"] < len(rep["candidates_ms_per_step"])
+    assert rep is not None and 1 <= len(rep["candidates_ms_per_step"]) <= 8 and 0 <= rep["kept"] < len(rep["candidates_ms_per_step"])
     assert all(ms > 0 for ms in rep["candidates_ms_per_step"])
     assert rep["candidates_ms_per_step"][rep["kept"]] <= min(rep["candidates_ms_per_step"]) * 1.006
     assert lbm.steps_done == 0 and lbm.state_total_max < 0
