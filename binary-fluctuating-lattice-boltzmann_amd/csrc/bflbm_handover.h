@@ -651,7 +651,8 @@ static inline hipError_t handover_launch(const double* S, double* D, const doubl
   Hg.use_frames = (sig_in.step == steps - 1 && sig_in.same_geometry(sig_out)) ? 1 : 0;
   dim3 grid((unsigned)(F.per_xcd * 8)), block(TX * TY);
   const uint32_t nidx = (uint32_t)steps;
-  const bool rag = handover_ragged(G);
+  static const bool force_rag = [] { const char* e = getenv("BFLBM_FORCE_RAG"); return e && atoi(e) != 0; }();   // diagnostics: what the ragged-tile code costs on full tiles
+  const bool rag = handover_ragged(G) || force_rag;
   if (mode == 1) { if (rag) hipLaunchKernelGGL((k_fused_ho<TY, 1, true>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
                    else     hipLaunchKernelGGL((k_fused_ho<TY, 1, false>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx); }
   else           { if (rag) hipLaunchKernelGGL((k_fused_ho<TY, 0, true>), grid, block, 0, stream, S, D, G, P, F, Hg, nidx);
