@@ -532,8 +532,19 @@ int bflbm_tune_placement(bflbm_ctx* c, int max_candidates, float* ms_per_step, i
   const Geo& G = c->G;
   const size_t sdoubles = (size_t)2 * Q * G.vol;
   const size_t state_bytes = (sdoubles + (size_t)(c->S[1] - c->S[0])) * sizeof(double);     // A, the displacement, B
+  // whatever happens below, the context leaves as freshly created: zeroed buffers (halo planes must never hold garbage), nothing resident
+  auto fresh = [&]() -> int {
+    (void)hipStreamSynchronize(c->stream);
+    const size_t bytes_now = (sdoubles + (size_t)(c->S[1] - c->S[0])) * sizeof(double);
+    HIP_TRY(hipMemsetAsync(c->S[0], 0, bytes_now, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->cur = 0; c->steps = 0; c->density_valid = false; c->step_open = false; c->com_valid = false; c->total_max = -1.;
+    c->ref_kind = 0; c->ref_kind_step = -1;
+    for (auto& b : c->fsig) for (auto& sg : b) sg = HoSig();
+    return 0;
+  };
   float best_ms = 0.f;
-  if (probe_ms(c, &best_ms)) return 1;
+  if (probe_ms(c, &best_ms)) { (void)fresh(); return 1; }
   if (ms_per_step) ms_per_step[0] = best_ms;
   c->tune_ms[0] = best_ms; c->tune_n = 1;
   int best = 0;
@@ -565,15 +576,10 @@ int bflbm_tune_placement(bflbm_ctx* c, int max_candidates, float* ms_per_step, i
       if (nS) hipFree(nS);
       if (nF) hipFree(nF);
       c->S[0] = oldS[0]; c->S[1] = oldS[1]; c->frames[0] = oldF[0]; c->frames[1] = oldF[1];
-      if (rc) return 1;
+      if (rc) { (void)fresh(); return 1; }
     }
   }
-  // back to the state of a fresh context: zeroed buffers (halo planes must never hold garbage), nothing resident
-  HIP_TRY(hipMemsetAsync(c->S[0], 0, state_bytes, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->cur = 0; c->steps = 0; c->density_valid = false; c->step_open = false; c->com_valid = false; c->total_max = -1.;
-  c->ref_kind = 0; c->ref_kind_step = -1;
-  for (auto& b : c->fsig) for (auto& sg : b) sg = HoSig();
+  if (fresh()) return 1;
   if (kept) *kept = best;
   c->tune_kept = best;
   return 0;
