@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-site counter table of tools/r4_pmc_sizes.sh: one row per lattice, counters of the step's kernel (k_fused_ho) divided by
+"""Per-site counter table of tools/round4/r4_pmc_sizes.sh: one row per lattice, counters of the step's kernel (k_fused_ho) divided by
 the sites one launch updates.  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B: /opt/skills/guides/
 MI355X_MICROARCH.md, HBM section), both sizes are KiB.  usage: pmc_per_site.py gpurun_out/r4_pmc_sizes"""
 import glob, json, os, re, sys

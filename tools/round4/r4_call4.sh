@@ -4,7 +4,7 @@ out=gpurun_out/r4_call4; rm -rf $out; mkdir -p $out
 B=binary-fluctuating-lattice-boltzmann_amd/csrc/build
 timeout -k 10 900 python -m pytest tests/test_gpu_handover_oracle.py tests/test_gpu_cpp_adapter.py tests/test_gpu_api.py -q -m gpu > $out/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest.log
 tail -8 $out/pytest.log
-tools/r4_pmc_sizes.sh > $out/pmc_sizes.log 2>&1; cp gpurun_out/r4_pmc_sizes/per_site_table.txt $out/; cat $out/per_site_table.txt
+tools/round4/r4_pmc_sizes.sh > $out/pmc_sizes.log 2>&1; cp gpurun_out/r4_pmc_sizes/per_site_table.txt $out/; cat $out/per_site_table.txt
 # chunk counts: BFLBM_FUSED_WG = tile columns x chunks.  512^3: 1024 columns; 256^3: 256 columns; 448^3: 784; 384^3: 576
 for cfg in "512 2048 4096 8192 16384" "256 256 512 1024 2048" "448 1568 3136 5488 6272 10976" "384 1152 2304 4608"; do
   set -- $cfg; s=$1; shift

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4, on the GPU box: parity of the new generator, then interleaved A/B of the noise-kernel variants.
-# usage: tools/r4_noise_ab.sh  (writes gpurun_out/r4_noise_ab/)
+# usage: tools/round4/r4_noise_ab.sh  (writes gpurun_out/r4_noise_ab/)
 out=gpurun_out/r4_noise_ab; mkdir -p $out
 B=binary-fluctuating-lattice-boltzmann_amd/csrc/build
 set -x

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4: the same counter set at 256^3, 384^3, 448^3, 512^3 and 1024x1024x64 in ONE session on ONE box,
 # quiet default schedule, one counter group per pass (never combined with tracing).  -> gpurun_out/r4_pmc_sizes/<size>/...
-# usage: tools/r4_pmc_sizes.sh
+# usage: tools/round4/r4_pmc_sizes.sh
 out=gpurun_out/r4_pmc_sizes; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for shape in 256,256,256 384,384,384 448,448,448 512,512,512 1024,1024,64; do
