@@ -51,6 +51,15 @@
 #ifndef BFLBM_HO_SPREAD_F
 #define BFLBM_HO_SPREAD_F 28
 #endif
+#ifndef BFLBM_HO_NT_STORES
+#define BFLBM_HO_NT_STORES 1
+#endif
+#ifndef BFLBM_HO_NT_LOADS
+#define BFLBM_HO_NT_LOADS 0
+#endif
+#ifndef BFLBM_HO_NT_FRAMES
+#define BFLBM_HO_NT_FRAMES 0     // experiment: the frame stores too
+#endif
 #ifndef BFLBM_HO_SPREAD_F1
 #define BFLBM_HO_SPREAD_F1 44     // noise kernel, round 4: with the 11-instruction normals one request every 44 VALU instructions is
 #endif                            // +2.3 % at 512^3 and +2.0 % at 256^3 (16 ... 32: -1 %, 56: 0, 68: +2.5 / +0.5 %); round 3's generator: every spacing lost
@@ -159,7 +168,11 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
   auto wrapx = [&](int v) { return v < 0 ? v + G.nx : (v >= G.nx ? v - G.nx : v); };
   auto wrapy = [&](int v) { return v < 0 ? v + G.ny : (v >= G.ny ? v - G.ny : v); };
   auto ld = [](const double* __restrict__ base, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff); };
-  auto st = [](double* __restrict__ base, unsigned boff, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v; };
+  auto ldnt = [](const double* __restrict__ base, unsigned boff) { return __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff)); };
+  auto st = [](double* __restrict__ base, unsigned boff, double v) {
+    double* q = reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff);
+    if (BFLBM_HO_NT_FRAMES) __builtin_nontemporal_store(v, q); else *q = v;
+  };
 
   // active extent of this tile; idle lanes / rows of a ragged tile work on a duplicate of the last active site
   const int aw = RAG ? min(TX, G.nx - x0) : TX, ah = RAG ? min(TY, G.ny - y0) : TY;
@@ -284,8 +297,11 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
       for (int i = 0; i < Q; ++i) {
         const double* __restrict__ b = pl[1 - Vel::cz[i]] + (long long)i * G.vol;
         const unsigned o = oo[1 - Vel::cy[i]][1 + BFLBM_PX(Vel::cx[i])];
-        if (which != 2) f[i] = ld(b, o);
-        if (which != 1) g[i] = ld(b + (long long)Q * G.vol, o);
+        // BFLBM_HO_NT_LOADS: 1 = the populations that do not travel in x with the non-temporal hint (every one of their lines is read by
+        // exactly one tile, once; only the x-shifted row segments of the others share a line with the neighbouring tile), 2 = all of them
+        const bool nt = BFLBM_HO_NT_LOADS == 2 || (BFLBM_HO_NT_LOADS == 1 && Vel::cx[i] == 0);
+        if (which != 2) f[i] = nt ? ldnt(b, o) : ld(b, o);
+        if (which != 1) g[i] = nt ? ldnt(b + (long long)Q * G.vol, o) : ld(b + (long long)Q * G.vol, o);
       }
     }
     if ((parts & 2) && which != 2 && Hg.use_frames && q >= fa && q <= fb && has_rtask) {
@@ -448,7 +464,14 @@ k_fused_ho(const double* __restrict__ S, double* __restrict__ D, Geo G, DevParam
         PopTerms T;
         d_population_terms(mom, T);
         double* __restrict__ Dk = Dp + (long long)(k * Q) * G.vol;
-        auto put = [&](int i, double v) { if (active) st(Dk + (long long)i * G.vol, os3[1 + BFLBM_SX(Vel::cx[i])], v); };
+        // population stores carry the non-temporal hint (round 4: +0.9 % at 512^3, +0.6 % at 256^3, +1.6 % with noise, runs agreeing to
+        // 0.1 %: the written lines are not read again before the next step, the L2 keeps the neighbours' shared lines instead)
+        auto put = [&](int i, double v) {
+          if (active) {
+            double* __restrict__ q = reinterpret_cast<double*>(reinterpret_cast<char*>(Dk + (long long)i * G.vol) + os3[1 + BFLBM_SX(Vel::cx[i])]);
+            if (BFLBM_HO_NT_STORES) __builtin_nontemporal_store(v, q); else *q = v;
+          }
+        };
         // x shifts see zeros from the idle lanes of a narrow tile (they hold a duplicate of the last site)
         auto shr = [&](double v) { return ho_shr((RAG && !active_x) ? 0.0 : v); };
         auto shl = [&](double v) { return ho_shl((RAG && !active_x) ? 0.0 : v); };
