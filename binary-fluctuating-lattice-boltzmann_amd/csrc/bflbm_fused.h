@@ -100,7 +100,13 @@ k_fused(const double* __restrict__ S, double* __restrict__ D,
   const unsigned xo[3] = { (unsigned)wrapx(x - 1) * 8u, (unsigned)x * 8u, (unsigned)wrapx(x + 1) * 8u };
   const unsigned yo[3] = { (unsigned)(wrapy(y - 1) * G.pitch) * 8u, (unsigned)(y * G.pitch) * 8u, (unsigned)(wrapy(y + 1) * G.pitch) * 8u };
   auto ld = [](const double* __restrict__ base, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff); };
-  auto st = [](double* __restrict__ base, unsigned boff, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v; };
+#ifndef BFLBM_FUSED_NT_STORES
+#define BFLBM_FUSED_NT_STORES 0     // non-temporal population stores: +0.8 % at 256^3, -2.0 % at 512^3 in this kernel (profiles/r04_nt_hints.txt): off
+#endif
+  auto st = [](double* __restrict__ base, unsigned boff, double v) {
+    double* q = reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff);
+    if (BFLBM_FUSED_NT_STORES) __builtin_nontemporal_store(v, q); else *q = v;
+  };
   // ---- ring half-task of this thread: lanes 0..nper-1 of every wave; the lower half of the waves sums
   // fluid f, the upper half fluid g, so the fluid (and with it the load base) is wave-uniform
   const int nring = 2 * (aw + 2) + 2 * ah;

@@ -69,6 +69,13 @@ __device__ __forceinline__ long long nb_off(const SiteIdx& I, int dx, int dy, in
   return I.row[dz+1][dy+1] + xx;
 }
 
+#ifndef BFLBM_COLLIDE_NT_STORES
+#define BFLBM_COLLIDE_NT_STORES 0   // non-temporal population stores in k_collide: +3.7 % at 32^3, +1 ... -2 % elsewhere (profiles/r04_nt_hints.txt): off
+#endif
+__device__ __forceinline__ void st_pop(double* __restrict__ base, unsigned boff, double v) {   // population stores of k_collide
+  double* q = reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff);
+  if (BFLBM_COLLIDE_NT_STORES) __builtin_nontemporal_store(v, q); else *q = v;
+}
 // f_i(x) = S_i(x - c_i)
 __device__ __forceinline__ void pull_site(const double* __restrict__ S, const Geo& G, const SiteIdx& I,
                                           double (&fs)[Q], double (&gs)[Q]) {
@@ -276,7 +283,7 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
     }
     d_populations(m, fs);
 #pragma unroll
-    for (int i = 0; i < Q; ++i) st_sb(Dp + (long long)i*G.vol, BFLBM_XSHIFT ? I.o[1][1 + BFLBM_SX(Vel::cx[i])] : o, fs[i]);
+    for (int i = 0; i < Q; ++i) st_pop(Dp + (long long)i*G.vol, BFLBM_XSHIFT ? I.o[1][1 + BFLBM_SX(Vel::cx[i])] : o, fs[i]);
   }
   {
     double m[Q];
@@ -294,7 +301,7 @@ __global__ void __launch_bounds__(256, BFLBM_COLLIDE_WAVES) k_collide(const doub
     }
     d_populations(m, gs);
 #pragma unroll
-    for (int i = 0; i < Q; ++i) st_sb(Dp + (long long)(i+Q)*G.vol, BFLBM_XSHIFT ? I.o[1][1 + BFLBM_SX(Vel::cx[i])] : o, gs[i]);
+    for (int i = 0; i < Q; ++i) st_pop(Dp + (long long)(i+Q)*G.vol, BFLBM_XSHIFT ? I.o[1][1 + BFLBM_SX(Vel::cx[i])] : o, gs[i]);
   }
 }
 
