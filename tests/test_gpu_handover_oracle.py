@@ -11,7 +11,10 @@ which the trajectory carries forward with its own conditioning.  What is asserte
   (3) for the listed cases (near-vacuum sites: a minority density of 1e-9 that changes sign, LBM_binary.H:246-247) the
       masked metric of tests/tolerances.py at 1e-12 AND the unmasked figures within 10 x the oracle's own response to
       a one-ulp perturbation of its initial state for the same case; the unmasked maxima are printed beside the masked;
-  (4) populations within 1e-13 of the oracle's.
+  (4) populations within 1e-13 of the oracle's;
+  (5) a run through a violent transient -- the demixing mixture of configs[4] (alpha0 = 2.5, kBT = 1e-5): velocities of
+      thousands of lattice units at near-vacuum sites, the oracle's OWN one-ulp response 1e-9 in the densities and 5e-3 cs in
+      the velocities within 100 steps -- stays within 10 x that response (`test_handover_through_spinodal_demixing`).
 `test_named_stress_cases` keeps the four diverging runs of round 2's stress.log.
 BFLBM_STRICT_COLLECT=<file> appends one JSON line per case and checkpoint (tests/golden/make_strict_exceptions.py turns
 the file into the committed list).
@@ -211,6 +214,45 @@ def test_handover_with_thermal_noise_against_the_oracle(pkg, ob, threads, shape,
         _tolerances(lbm.LBM_hydrovars(), ref.h, f"{shape} {par}")
         assert np.abs(fn).max() > 1e-4
         lbm.close()
+
+
+def test_handover_through_spinodal_demixing(pkg, ob, threads):
+    """Clause (5) of the contract.  LBM_init_mixture with kBT = 1e-5 at alpha0 = 2.5 (interaction strength 5, inside `auto`'s
+    bound; bench.py's configs[4] case) demixes within 100 steps: rho from 1 to [-0.2, 5.4], |u| up to 1e4 lattice units where a
+    fluid is almost absent.  Such a run is ill-conditioned in the reference itself -- the oracle answers a one-ulp change of its
+    initial populations with 1e-10 in the masked metric, 1e-7 relative in the densities and 5e-3 cs in the velocities at
+    every site -- so the 1e-12 clauses cannot hold for ANY implementation that rounds differently; what is asserted is that
+    schedule 3 stays within 10 x the oracle's own response (its running maximum: one perturbation is one sample of it), that
+    the first step is bit-equal, and that the regime is what the docstring says (or the test would prove nothing)."""
+    shape, par = (128, 28, 26), dict(kBT=1e-5, alpha0=2.5)
+    ref = ob.OracleLattice(*shape, params=ob.default_params(**par)); ref.init_mixture()
+    per = ob.OracleLattice(*shape, params=ob.default_params(**par)); per.init_mixture()
+    rng = np.random.default_rng(1)
+    per.f *= 1.0 + rng.integers(-1, 2, per.f.shape) * 2.0 ** -52
+    per.g *= 1.0 + rng.integers(-1, 2, per.g.shape) * 2.0 ** -52
+    per.refresh("absolute")
+    lbm = pkg.BinaryLBM(*shape, params=pkg.default_params(**par), schedule="handover")
+    lbm.LBM_init_mixture()
+    assert lbm.resolved_schedule() == "handover"
+    ref.timestep(); per.timestep(); lbm.LBM_timestep(1)
+    f, g = lbm.populations()
+    assert np.array_equal(f, ref.f) and np.array_equal(g, ref.g)
+    keys = tolerances.MASKED + ("dens_elem_all", "vel_abs_all")
+    own = {k: 0.0 for k in keys}
+    done, violent = 1, False
+    for steps in range(20, 121, 20):
+        for _ in range(steps - done):
+            ref.timestep(); per.timestep()
+        lbm.LBM_timestep(steps - done); done = steps
+        e, k1 = tolerances.errors(lbm.LBM_hydrovars(), ref.h), tolerances.errors(per.h, ref.h)
+        for k in keys:
+            own[k] = max(own[k], k1[k])
+            assert e[k] <= max(1e-12, YARDSTICK * own[k]), f"step {steps} {k}: GPU {e[k]:.2e} against the oracle's own one-ulp response {own[k]:.2e}"
+        violent = violent or max(k1[k] for k in tolerances.MASKED) > 1e-11
+        if steps == 20:
+            assert all(e[k] <= 1e-12 for k in keys), e            # before the demixing the strict form holds
+    assert violent and np.abs(ref.h[2:5]).max() > 10.0 and ref.h[0].min() < 0.0 and np.isfinite(ref.h[:9]).all()
+    lbm.close()
 
 
 def test_handover_against_committed_oracle_trajectories(pkg):
