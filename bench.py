@@ -16,11 +16,12 @@ N > 1, who does what (the reference distributes boxes over MPI ranks, main_run_j
 with FillBoundary, LBM_binary.H:553-555):
   * launched by hand (`python bench.py --gpus N`): starts `torch.distributed.run` with N ranks of this file;
   * a rank started by torch.distributed.run is a SUPERVISOR: it never touches the GPU.  The supervisors form a gloo
-    group, and for each halo transport of the chain (--transport auto: rccl -> peer-kernel -> peer-copy -> rccl-direct)
+    group, and for each halo transport of the chain (--transport auto: rccl -> peer-copy -> peer-kernel -> rccl-direct)
     they start FRESH worker processes on a fresh rendezvous port, watch them under a wall-clock limit, agree on the
     outcome, and kill the workers (their own process groups) when one failed or the limit passed.  The first transport
     that completes produces the line; config.launcher says which ones were tried.  An RCCL failure is usually a hang or
-    an abort in one rank, which a retry inside the ranks cannot survive -- hence fresh processes;
+    an abort in one rank, which a retry inside the ranks cannot survive -- hence fresh processes.  --second-transport also
+    times the next transport family beside the first (config.second_transport; off by default);
   * a WORKER (BFLBM_BENCH_WORKER=1) does the measurement: transports `rccl` (pack, one message per face, unpack) and
     `rccl-direct` (38 plane-sized sends per face straight from the state) run one process per GPU over
     torch.distributed; `peer-kernel` / `peer-copy` run ONE process that drives all N GPUs through the C-ABI's ring
@@ -46,7 +47,7 @@ BYTES_PER_LUP = 608.0          # 2 fluids x 19 populations x 8 B x (1 read + 1 w
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 REFERENCE_PROBE_MLUPS = 0.38   # the reference's own headers behind a container shim, 1 core (survey host)
 
-TRANSPORT_CHAIN = ["rccl", "peer-kernel", "peer-copy", "rccl-direct"]
+TRANSPORT_CHAIN = ["rccl", "peer-copy", "peer-kernel", "rccl-direct"]   # after RCCL the most standard multi-GPU operation HIP has (peer copies), then peer reads by a kernel
 TRANSPORT_TEXT = {
     "rccl": "rccl, staged (pack, one message per face, unpack)",
     "rccl-direct": "rccl, direct (38 plane-sized sends per face from the state buffers)",
@@ -128,8 +129,11 @@ def parse_args():
                     help="N > 1: auto (the chain " + " -> ".join(TRANSPORT_CHAIN) + ", first that completes), one of them, or a comma list")
     ap.add_argument("--attempt-timeout", type=float, default=420.0, help="N > 1: wall-clock limit of one transport attempt, seconds")
     ap.add_argument("--no-overlap-leg", action="store_true", help="N > 1: skip the informational steps with the exchange after the sweep")
-    ap.add_argument("--no-second-transport", action="store_true",
-                    help="N > 1, --transport auto: do not time the next transport family as an informational leg")
+    ap.add_argument("--second-transport", action="store_true", default=os.environ.get("BFLBM_BENCH_SECOND_TRANSPORT", "0") == "1",
+                    help="N > 1, --transport auto: after the first transport completed, time the next transport FAMILY as an informational "
+                         "leg (config.second_transport).  Off by default: a transport that has never run on several GPUs should not get "
+                         "the chance to disturb the node in the middle of a scaling series once a result exists")
+    ap.add_argument("--no-second-transport", action="store_true", help="(kept for older command lines; the leg is off unless --second-transport)")
     return ap.parse_args()
 
 
@@ -234,7 +238,7 @@ def supervise(a):
     # Informational: the next transport FAMILY (peer after rccl, rccl after peer) in the same run, when the first attempt left
     # time for it -- the driver's scaling run is the only multi-GPU measurement a round gets.  Never allowed to cost the line.
     second = None
-    if done and a.transport == "auto" and not a.no_second_transport:
+    if done and a.transport == "auto" and a.second_transport and not a.no_second_transport:
         fam = tried[-1]["transport"].split("-")[0]
         alt = next((t for t in TRANSPORT_CHAIN if t.split("-")[0] != fam and t not in [x["transport"] for x in tried]), None)
         go = [alt is not None and time.time() - t_begin < 200.0]

@@ -34,29 +34,37 @@ def _no_leftover_workers():
 
 
 def test_first_transport_completes_and_the_next_family_is_timed_beside_it():
-    out, lines = _run({})
+    out, lines = _run({}, args=("--second-transport",))
     assert out.returncode == 0, out.stderr[-2000:]
     assert len(lines) == 1, out.stdout                     # ONE line on stdout, whatever the workers printed
     r = json.loads(lines[0])
     tried = r["config"]["launcher"]["transports_tried"]
-    assert [t["transport"] for t in tried] == ["rccl", "peer-kernel"] and all(t["ok"] for t in tried)
+    assert [t["transport"] for t in tried] == ["rccl", "peer-copy"] and all(t["ok"] for t in tried)
     assert tried[1].get("informational") is True
     assert r["config"]["halo_transport"].startswith("rccl, staged")
     assert r["config"]["second_transport"]["halo_transport"].startswith("peer")
     assert r["n_gpus"] == 2
 
 
+def test_by_default_only_the_first_transport_that_completes_runs():
+    out, lines = _run({})
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(lines[0])
+    assert [t["transport"] for t in r["config"]["launcher"]["transports_tried"]] == ["rccl"]
+    assert "second_transport" not in r["config"]
+
+
 def test_a_failing_and_a_hanging_transport_are_replaced_by_fresh_workers():
     """rccl: the last rank exits with an error before the rendezvous (its peer would wait for it for ever);
-    peer-kernel: the single worker never finishes (killed at the limit); peer-copy completes and produces the line."""
-    out, lines = _run({"BFLBM_BENCH_FAIL": "rccl:exit,peer-kernel:hang"}, args=("--attempt-timeout", "6.5", "--no-second-transport"), by_hand=True)
+    peer-copy: the single worker never finishes (killed at the limit); peer-kernel completes and produces the line."""
+    out, lines = _run({"BFLBM_BENCH_FAIL": "rccl:exit,peer-copy:hang"}, args=("--attempt-timeout", "6.5", "--no-second-transport"), by_hand=True)
     assert out.returncode == 0, out.stderr[-2000:]
     assert len(lines) == 1, out.stdout
     r = json.loads(lines[0])
     tried = r["config"]["launcher"]["transports_tried"]
-    assert [(t["transport"], t["ok"]) for t in tried] == [("rccl", False), ("peer-kernel", False), ("peer-copy", True)]
+    assert [(t["transport"], t["ok"]) for t in tried] == [("rccl", False), ("peer-copy", False), ("peer-kernel", True)]
     assert "exited with an error" in tried[0]["note"] and "limit" in tried[1]["note"]
-    assert r["config"]["halo_transport"].startswith("peer, one process drives all GPUs; copy engine")
+    assert r["config"]["halo_transport"].startswith("peer, one process drives all GPUs; a gather kernel")
     assert "FAILED" in out.stderr
     _no_leftover_workers()
 

@@ -242,28 +242,27 @@ def test_bench_two_slabs_on_one_gpu_default_chain():
     """The N > 1 bench path with the hand-over schedule (what auto runs on the 512^3 slabs of the real bench) as the driver
     starts it: the first transport of the chain (rccl, staged) produces the line -- one JSON line with n_gpus 2, the stripe's
     mass conserved, the halo size and the transport stated, the exchange-after-sweep leg timed -- and the next transport
-    family (the native ring with in-place peer reads, one process) is timed beside it as an informational leg."""
-    r, _ = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--shape", "128,16,12", "--schedule", "handover"])
+    family (the native ring with the copy engine, one process) is timed beside it as an informational leg (--second-transport)."""
+    r, _ = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--shape", "128,16,12", "--schedule", "handover", "--second-transport"])
     _check_line(r, "rccl, staged")
     tried = r["config"]["launcher"]["transports_tried"]
-    assert [(t["transport"], t["ok"]) for t in tried] == [("rccl", True), ("peer-kernel", True)]
+    assert [(t["transport"], t["ok"]) for t in tried] == [("rccl", True), ("peer-copy", True)]
     second = r["config"]["second_transport"]
-    assert "a gather kernel reads" in second["halo_transport"] and "4 faces by kernel, 0 by copies" in second["halo_transport"]
+    assert "copy engine" in second["halo_transport"] and "0 faces by kernel, 4 by copies" in second["halo_transport"]
     assert second["value"] > 0 and second["halo_overlap"]["ms_per_step_exchange_after_sweep"] > 0
 
 
 def test_bench_falls_back_to_fresh_workers_with_the_next_transports():
-    """rccl: the last rank dies before the rendezvous (what an RCCL abort looks like from outside); peer-kernel: its one worker
+    """rccl: the last rank dies before the rendezvous (what an RCCL abort looks like from outside); peer-copy: its one worker
     exits with an error.  The supervisors end what is left, start fresh workers with the next transport each time, the
-    copy-engine ring (the CU-free transport) produces the line, and the remaining family member (rccl, direct: 38
-    plane-sized sends per face) is timed beside it -- so all four transports have run on this GPU between this test and the
-    previous one."""
-    r, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "128,16,12", "--schedule", "handover"],
-                    env={"BFLBM_BENCH_FAIL": "rccl:exit,peer-kernel:exit"})
-    _check_line(r, "copy engine")
-    assert "0 faces by kernel, 4 by copies" in r["config"]["halo_transport"]
+    ring with in-place peer reads produces the line, and the remaining family member (rccl, direct: 38 plane-sized sends
+    per face) is timed beside it -- so all four transports have run on this GPU between this test and the previous one."""
+    r, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "128,16,12", "--schedule", "handover", "--second-transport"],
+                    env={"BFLBM_BENCH_FAIL": "rccl:exit,peer-copy:exit"})
+    _check_line(r, "a gather kernel reads")
+    assert "4 faces by kernel, 0 by copies" in r["config"]["halo_transport"]
     tried = r["config"]["launcher"]["transports_tried"]
-    assert [(t["transport"], t["ok"]) for t in tried] == [("rccl", False), ("peer-kernel", False), ("peer-copy", True), ("rccl-direct", True)]
+    assert [(t["transport"], t["ok"]) for t in tried] == [("rccl", False), ("peer-copy", False), ("peer-kernel", True), ("rccl-direct", True)]
     assert "rccl, direct" in r["config"]["second_transport"]["halo_transport"]
     assert err.count("FAILED") == 2
 
